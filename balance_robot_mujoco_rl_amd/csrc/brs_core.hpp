@@ -1,0 +1,1158 @@
+// brs_core.hpp -- one environment instance of the balance-robot simulator, written for ONE GPU LANE.
+//
+// The HIP kernel (brs_kernels.hip) instantiates this with R = float, one wavefront lane per env, state in
+// VGPRs for the whole env step (250 substeps fused), the per-lane contact list in LDS (lane-strided
+// columns, conflict-free ds_read_b32).  The same source compiles on the host (tests/hostsim) with
+// R = float or double so the algorithm can be checked against oracle/ without a GPU; that host build is
+// test infrastructure and is never loaded by the product.
+//
+// What one substep is (the reference's hot call: mujoco.mj_step, envs/env01_v2.py:37):
+//   kinematics -> smooth forces (gravity/gyroscopic bias, wheel damping, clamped velocity servos)
+//   -> plane-cylinder / plane-box collision -> pyramidal-cone soft constraints (4 rows per contact)
+//   -> Newton solve of the convex acceleration problem -> implicitfast -> semi-implicit advance.
+// Formulation here (NOT MuJoCo's): the robot is a gyrostat; in body-frame linear coordinates its 8x8
+// mass matrix is CONSTANT and sparse (closed-form inverse); all floor contacts share the world-aligned
+// frame; the block (Env03) is an isotropic free body; robot and block systems are solved separately
+// (8x8 and 6x6 Cholesky in registers) unless a block<->robot contact couples them (14x14).
+#pragma once
+#include "brs_model.hpp"
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define BRS_HD __host__ __device__ __forceinline__
+#else
+#define BRS_HD inline
+#endif
+
+namespace brs {
+
+// ------------------------------------------------------------------------------------ math wrappers
+BRS_HD float sqrt_(float x) { return sqrtf(x); }
+BRS_HD double sqrt_(double x) { return sqrt(x); }
+BRS_HD float rsqrt_(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return rsqrtf(x);
+#else
+  return 1.0f / sqrtf(x);
+#endif
+}
+BRS_HD double rsqrt_(double x) { return 1.0 / sqrt(x); }
+BRS_HD float rcp_(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __frcp_rn(x);
+#else
+  return 1.0f / x;
+#endif
+}
+BRS_HD double rcp_(double x) { return 1.0 / x; }
+BRS_HD float abs_(float x) { return fabsf(x); }
+BRS_HD double abs_(double x) { return fabs(x); }
+BRS_HD float atan2_(float y, float x) { return atan2f(y, x); }
+BRS_HD double atan2_(double y, double x) { return atan2(y, x); }
+BRS_HD void sincos_(float x, float* s, float* c) { *s = sinf(x); *c = cosf(x); }
+BRS_HD void sincos_(double x, double* s, double* c) { *s = sin(x); *c = cos(x); }
+template <typename R> BRS_HD R max_(R a, R b) { return a > b ? a : b; }
+template <typename R> BRS_HD R min_(R a, R b) { return a < b ? a : b; }
+
+template <typename R> BRS_HD R pick3(int k, R a, R b, R c) { return k == 0 ? a : (k == 1 ? b : c); }
+template <typename R> BRS_HD R pick3(int k, const R* v) { return k == 0 ? v[0] : (k == 1 ? v[1] : v[2]); }
+template <typename R> BRS_HD void cross_(const R* a, const R* b, R* o) {
+  R x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+template <typename R> BRS_HD R dot_(const R* a, const R* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+// rotation matrix (row-major, body->world) of a unit quaternion (w,x,y,z)
+template <typename R> BRS_HD void quat2mat_(const R* q, R* M) {
+  R w = q[0], x = q[1], y = q[2], z = q[3];
+  M[0] = 1 - 2 * (y * y + z * z); M[1] = 2 * (x * y - w * z);     M[2] = 2 * (x * z + w * y);
+  M[3] = 2 * (x * y + w * z);     M[4] = 1 - 2 * (x * x + z * z); M[5] = 2 * (y * z - w * x);
+  M[6] = 2 * (x * z - w * y);     M[7] = 2 * (y * z + w * x);     M[8] = 1 - 2 * (x * x + y * y);
+}
+template <typename R> BRS_HD void mulT_(const R* M, const R* v, R* o) {  // o = M^T v
+  R x = M[0] * v[0] + M[3] * v[1] + M[6] * v[2], y = M[1] * v[0] + M[4] * v[1] + M[7] * v[2],
+    z = M[2] * v[0] + M[5] * v[1] + M[8] * v[2];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+template <typename R> BRS_HD void mul_(const R* M, const R* v, R* o) {  // o = M v
+  R x = M[0] * v[0] + M[1] * v[1] + M[2] * v[2], y = M[3] * v[0] + M[4] * v[1] + M[5] * v[2],
+    z = M[6] * v[0] + M[7] * v[1] + M[8] * v[2];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+
+// fp64 quaternion advance q <- normalise(q) * exp(h * w / 2)  (MuJoCo mju_quatIntegrate), series in
+// u = (h|w|/2)^2 (h|w| <= ~1e-2, so u^4 terms are < 1e-20); q stays unit to rounding, the renormalisation
+// is a 2-term series as well -- no fp64 sqrt/div on the GPU.
+BRS_HD void quat_advance(double* q, double wx, double wy, double wz, double h) {
+  double hh = 0.5 * h, u = hh * hh * (wx * wx + wy * wy + wz * wz);
+  double c = 1.0 + u * (-0.5 + u * (1.0 / 24.0 - u * (1.0 / 720.0)));
+  double s = hh * (1.0 + u * (-1.0 / 6.0 + u * (1.0 / 120.0 - u * (1.0 / 5040.0))));
+  double rx = s * wx, ry = s * wy, rz = s * wz;
+  double e = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3] - 1.0;
+  double k = 1.0 + e * (-0.5 + 0.375 * e);
+  double w0 = q[0] * k, x0 = q[1] * k, y0 = q[2] * k, z0 = q[3] * k;
+  q[0] = w0 * c - x0 * rx - y0 * ry - z0 * rz;
+  q[1] = w0 * rx + x0 * c + y0 * rz - z0 * ry;
+  q[2] = w0 * ry - x0 * rz + y0 * c + z0 * rx;
+  q[3] = w0 * rz + x0 * ry - y0 * rx + z0 * c;
+}
+
+// ------------------------------------------------------------------------------------ Philox4x32-10
+// counter = (n, 0, env_gid_lo, env_gid_hi), key = seed; identical in oracle/brs_oracle.c
+BRS_HD void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* o) {
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+
+// per-event uniform stream of one env: blocks are drawn lazily, leftovers are discarded at event end
+template <typename R> struct Stream {
+  uint64_t seed;
+  int64_t gid;
+  uint32_t ctr;  // next unused Philox block of this env (persistent per env)
+  uint32_t b0, b1, b2, b3;
+  int pos;
+  const double* script;  // host test hook: scripted uniforms (always null on the GPU)
+  int script_n, script_pos;
+  BRS_HD void open(uint64_t s, int64_t g, uint32_t c) { seed = s; gid = g; ctr = c; pos = 4; b0 = b1 = b2 = b3 = 0; script = nullptr; script_n = script_pos = 0; }
+  BRS_HD R next() {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    if (script && script_pos < script_n) return (R)script[script_pos++];
+#endif
+    if (pos == 4) {
+      uint32_t o[4];
+      philox4x32_10(ctr, 0u, (uint32_t)((uint64_t)gid & 0xffffffffu), (uint32_t)((uint64_t)gid >> 32),
+                    (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), o);
+      b0 = o[0]; b1 = o[1]; b2 = o[2]; b3 = o[3];
+      ctr++; pos = 0;
+    }
+    uint32_t x = pos == 0 ? b0 : (pos == 1 ? b1 : (pos == 2 ? b2 : b3));
+    pos++;
+    return (R)(x >> 8) * (R)(1.0 / 16777216.0);
+  }
+};
+
+// ------------------------------------------------------------------------------------ per-lane contact store
+// 8 words per slot; word w of slot s lives at base[(s*8+w)*stride] (GPU: stride 64 = one LDS row per word)
+enum { SLOT_ROBOT = 0, N_ROBOT_SLOTS = 8, SLOT_BLOCK = 8, N_BLOCK_SLOTS = 4, SLOT_COUPLED = 12, N_COUPLED_SLOTS = 6,
+       N_SLOTS_ENV01 = 8, N_SLOTS_ENV03 = 18, SLOT_WORDS = 8 };
+template <typename R> struct Store {
+  R* base;
+  int stride;
+  BRS_HD R get(int s, int w) const { return base[(s * SLOT_WORDS + w) * stride]; }
+  BRS_HD void set(int s, int w, R v) { base[(s * SLOT_WORDS + w) * stride] = v; }
+};
+// meta word (kept as an exactly-representable small number): sel | maskNew<<2 | maskH<<6
+BRS_HD int meta_sel(int m) { return m & 3; }
+BRS_HD int meta_new(int m) { return (m >> 2) & 15; }
+BRS_HD int meta_h(int m) { return (m >> 6) & 31; }
+BRS_HD int meta_make(int sel, int mnew, int mh) { return sel | (mnew << 2) | (mh << 6); }
+
+// ------------------------------------------------------------------------------------ env state (registers)
+template <typename R, bool BLK> struct EnvState {
+  static constexpr int NV = BLK ? 14 : 8;
+  double p[3], q[4], th[2];  // torso position, unit quaternion (w,x,y,z), wheel angles  (fp64 accumulators)
+  R v[3], w[3], ww[2];       // world-frame linear velocity, BODY-frame angular velocity, wheel rates
+  double bp[3], bq[4];       // block pose
+  R bv[3], bw[3];            // block: world linear, body angular
+  R a[NV];                   // solver variable / warm start, BODY-frame linear coordinates (robot and block)
+  double time;
+  // accessor pose: what data.body("robot_body").xquat/.xpos would read (kinematics of the last forward pass)
+  double xq[4], xp[3];
+  // env-level
+  R last_pitch;
+  double block_timer;  // < 0 : None
+  int elapsed;
+  uint32_t rng_ctr;
+  int side_front;
+  R ep_return;
+  int bad;
+};
+
+template <typename R> BRS_HD R impedance_(const ContactClass<R>& c, R dist) {
+  if (c.inv_width == (R)0) return c.d0;
+  R x = (c.margin - dist) * c.inv_width;  // >= 0 for an active contact
+  x = min_(x, (R)1);
+  R y = x <= (R)0.5 ? 2 * x * x : 1 - 2 * (1 - x) * (1 - x);
+  return c.d0 + y * (c.d1 - c.d0);
+}
+
+// closed-form solve of (M_b + diag(0..0,dL,dR)) x = f for the robot (body coordinates)
+template <typename R> BRS_HD void msolve_(const Params<R>& P, const R* f, R dL, R dR, R* x) {
+  x[2] = f[2] * P.inv_m;
+  x[5] = f[5] * P.inv_Izz;
+  x[0] = (P.Iyy * f[0] - P.mcz * f[4]) * P.inv_det_xy;
+  x[4] = (P.m * f[4] - P.mcz * f[0]) * P.inv_det_xy;
+  R iL = rcp_(P.Ia + dL), iR = rcp_(P.Ia + dR);
+  R red = P.Ixx - P.Ia * P.Ia * (iL + iR) - P.mcz * P.cz;
+  x[3] = (f[3] + P.Ia * (f[6] * iL - f[7] * iR) + P.cz * f[1]) * rcp_(red);
+  x[1] = (f[1] + P.mcz * x[3]) * P.inv_m;
+  x[6] = (f[6] + P.Ia * x[3]) * iL;
+  x[7] = (f[7] - P.Ia * x[3]) * iR;
+}
+template <typename R> BRS_HD void msolve0_(const Params<R>& P, const R* f, R* x) {  // dL = dR = 0
+  x[2] = f[2] * P.inv_m;
+  x[5] = f[5] * P.inv_Izz;
+  x[0] = (P.Iyy * f[0] - P.mcz * f[4]) * P.inv_det_xy;
+  x[4] = (P.m * f[4] - P.mcz * f[0]) * P.inv_det_xy;
+  x[3] = (f[3] + (f[6] - f[7]) + P.cz * f[1]) * rcp_(P.Ixx_red0);
+  x[1] = (f[1] + P.mcz * x[3]) * P.inv_m;
+  x[6] = f[6] * P.inv_Ia + x[3];
+  x[7] = f[7] * P.inv_Ia - x[3];
+}
+// y = M_b x (robot)
+template <typename R> BRS_HD void mmul_(const Params<R>& P, const R* x, R* y) {
+  y[0] = P.m * x[0] + P.mcz * x[4];
+  y[1] = P.m * x[1] - P.mcz * x[3];
+  y[2] = P.m * x[2];
+  y[3] = -P.mcz * x[1] + P.Ixx * x[3] + P.Ia * (x[7] - x[6]);
+  y[4] = P.mcz * x[0] + P.Iyy * x[4];
+  y[5] = P.Izz * x[5];
+  y[6] = P.Ia * (x[6] - x[3]);
+  y[7] = P.Ia * (x[7] + x[3]);
+}
+
+// packed lower-triangular index
+BRS_HD constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }
+
+// in-place Cholesky of the [N0,N1) diagonal block of a packed symmetric matrix, then solve H x = b on it.
+// inv-diagonals are kept in dinv.  All indices are compile-time after unrolling (registers, no scratch).
+template <typename R, int N0, int N1> BRS_HD void chol_solve_block(R* H, const R* b, R* x) {
+  R dinv[N1 - N0];
+#pragma unroll
+  for (int j = N0; j < N1; j++) {
+    R s = H[tri(j, j)];
+#pragma unroll
+    for (int k = N0; k < j; k++) s -= H[tri(j, k)] * H[tri(j, k)];
+    s = max_(s, (R)1e-30);
+    R inv = rsqrt_(s);
+    dinv[j - N0] = inv;
+#pragma unroll
+    for (int i = j + 1; i < N1; i++) {
+      R t = H[tri(i, j)];
+#pragma unroll
+      for (int k = N0; k < j; k++) t -= H[tri(i, k)] * H[tri(j, k)];
+      H[tri(i, j)] = t * inv;
+    }
+  }
+  R y[N1 - N0];
+#pragma unroll
+  for (int i = N0; i < N1; i++) {
+    R s = b[i];
+#pragma unroll
+    for (int k = N0; k < i; k++) s -= H[tri(i, k)] * y[k - N0];
+    y[i - N0] = s * dinv[i - N0];
+  }
+#pragma unroll
+  for (int i = N1 - 1; i >= N0; i--) {
+    R s = y[i - N0];
+#pragma unroll
+    for (int k = i + 1; k < N1; k++) s -= H[tri(k, i)] * x[k];
+    x[i] = s * dinv[i - N0];
+  }
+}
+
+// ------------------------------------------------------------------------------------ one substep
+template <typename R, bool BLK> struct Sim {
+  static constexpr int NV = BLK ? 14 : 8;
+  static constexpr int NH = NV * (NV + 1) / 2;
+  using ES = EnvState<R, BLK>;
+
+  // per-substep frame data shared by the passes
+  struct Frame {
+    R RT[9];           // torso body->world
+    R nT[3], t1T[3], t2T[3];  // world +z, +y, -x expressed in the torso frame (floor contact frame)
+    R RB[9], nB[3], t1B[3], t2B[3];
+    R dTB[3];          // x_T - x_B (world), for coupled contacts
+    R a0[NV];          // unconstrained acceleration (body coords)
+    int nfr, nfb, nc;  // robot-floor, block-floor, coupled contact counts of this lane
+  };
+
+  // wheel hinge column for a contact at r (torso frame) on wheel sel (1 L: axis -x at (-px,0,pz); 2 R: +x at (+px,0,pz))
+  static BRS_HD void wheel_col(const Params<R>& P, int sel, const R* r, R* wc) {
+    R s = sel == 1 ? (R)-1 : (sel == 2 ? (R)1 : (R)0);
+    R dy = r[1], dz = r[2] - P.wheel_pz;
+    wc[0] = 0; wc[1] = -s * dz; wc[2] = s * dy;  // (s e_x) x (d)
+  }
+
+  static BRS_HD void add_robot_floor(const Params<R>& P, Store<R>& st, Frame& F, const R* u, const R* w, const R* ww,
+                                     int sel, int cls, const R* pt, R dist) {
+    if (F.nfr >= N_ROBOT_SLOTS) return;
+    const ContactClass<R>& c = P.cc[cls];
+    R r[3] = {pt[0] - F.nT[0] * dist * (R)0.5, pt[1] - F.nT[1] * dist * (R)0.5, pt[2] - F.nT[2] * dist * (R)0.5};
+    // point velocity in the torso frame
+    R wc[3], wr[3];
+    wheel_col(P, sel, r, wc);
+    cross_(w, r, wr);
+    R wsel = sel == 1 ? ww[0] : (sel == 2 ? ww[1] : (R)0);
+    R pv[3] = {u[0] + wr[0] + wsel * wc[0], u[1] + wr[1] + wsel * wc[1], u[2] + wr[2] + wsel * wc[2]};
+    R vn = dot_(F.nT, pv), vt1 = dot_(F.t1T, pv), vt2 = dot_(F.t2T, pv);
+    R imp = impedance_(c, dist);
+    int s = SLOT_ROBOT + F.nfr;
+    st.set(s, 0, r[0]); st.set(s, 1, r[1]); st.set(s, 2, r[2]);
+    st.set(s, 3, -c.B * vn - c.K * imp * (dist - c.margin));
+    st.set(s, 4, -c.B * c.mu * vt1);
+    st.set(s, 5, -c.B * c.mu * vt2);
+    st.set(s, 6, imp * rcp_((1 - imp) * c.cD));
+    st.set(s, 7, (R)meta_make(sel, 0, 16));
+    F.nfr++;
+  }
+
+  // plane <-> cylinder (the two wheels), restating MuJoCo's primitive in the torso frame
+  static BRS_HD void collide_wheel(const Params<R>& P, Store<R>& st, Frame& F, const R* u, const R* w, const R* ww,
+                                   R zT, int sel, bool triangles) {
+    const ContactClass<R>& c = P.cc[CC_WHEEL_FLOOR];
+    R px = sel == 1 ? -P.wheel_px : P.wheel_px, pz = P.wheel_pz;
+    R nx = F.nT[0], ny = F.nT[1], nz = F.nT[2];
+    R len = sqrt_(ny * ny + nz * nz);
+    R vy, vz;
+    if (len >= (R)1e-15) { R k = P.wheel_r * rcp_(len); vy = -ny * k; vz = -nz * k; }
+    else { vy = 0; vz = -P.wheel_r; }
+    R sg = nx > 0 ? (R)-1 : (R)1;  // cylinder axis (body x) flipped to point towards the plane
+    R axh = sg * P.wheel_hl, prjaxis = -abs_(nx) * P.wheel_hl, prjvec = vy * ny + vz * nz;
+    R dist0 = zT + nx * px + nz * pz;
+    R d1 = dist0 + prjaxis + prjvec;
+    if (!(d1 < c.margin)) return;
+    if (!triangles) {
+      R p1[3] = {px + axh, vy, pz + vz};
+      add_robot_floor(P, st, F, u, w, ww, sel, CC_WHEEL_FLOOR, p1, d1);
+      R d2 = dist0 - prjaxis + prjvec;
+      if (d2 < c.margin) {
+        R p2[3] = {px - axh, vy, pz + vz};
+        add_robot_floor(P, st, F, u, w, ww, sel, CC_WHEEL_FLOOR, p2, d2);
+      }
+    } else {
+      R dT = dist0 + prjaxis - (R)0.5 * prjvec;
+      if (dT < c.margin) {
+        const R k = (R)0.86602540378443864676;  // sqrt(3)/2 ; vec1 = sg*k*(0, vz, -vy)
+        R pa[3] = {px + axh, sg * k * vz - (R)0.5 * vy, pz - sg * k * vy - (R)0.5 * vz};
+        add_robot_floor(P, st, F, u, w, ww, sel, CC_WHEEL_FLOOR, pa, dT);
+        R pb[3] = {px + axh, -sg * k * vz - (R)0.5 * vy, pz + sg * k * vy - (R)0.5 * vz};
+        add_robot_floor(P, st, F, u, w, ww, sel, CC_WHEEL_FLOOR, pb, dT);
+      }
+    }
+  }
+
+  // plane <-> torso box: corners below the centre with dist < margin, at most 4 (MuJoCo's plane-box primitive)
+  static BRS_HD void collide_torso(const Params<R>& P, Store<R>& st, Frame& F, const R* u, const R* w, const R* ww, R zT) {
+    const ContactClass<R>& c = P.cc[CC_TORSO_FLOOR];
+    R nx = F.nT[0], ny = F.nT[1], nz = F.nT[2];
+    R dc = zT + nz * P.torso_cz;
+    // cheap reject: lowest corner
+    R low = dc - (abs_(nx) * P.torso_sx + abs_(ny) * P.torso_sy + abs_(nz) * P.torso_sz);
+    if (!(low < c.margin)) return;
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      R lx = (i & 1) ? P.torso_sx : -P.torso_sx, ly = (i & 2) ? P.torso_sy : -P.torso_sy, lz = (i & 4) ? P.torso_sz : -P.torso_sz;
+      R ld = nx * lx + ny * ly + nz * lz;
+      R d = dc + ld;
+      if (d < c.margin && ld <= 0 && cnt < 4) {
+        R pt[3] = {lx, ly, P.torso_cz + lz};
+        add_robot_floor(P, st, F, u, w, ww, 0, CC_TORSO_FLOOR, pt, d);
+        cnt++;
+      }
+    }
+  }
+
+  static BRS_HD void collide_block_floor(const Params<R>& P, Store<R>& st, Frame& F, const R* uB, const R* wB, R zB) {
+    const ContactClass<R>& c = P.cc[CC_BLOCK_FLOOR];
+    R nx = F.nB[0], ny = F.nB[1], nz = F.nB[2], s = P.block_s;
+    R low = zB - (abs_(nx) + abs_(ny) + abs_(nz)) * s;
+    if (!(low < c.margin)) return;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      R lx = (i & 1) ? s : -s, ly = (i & 2) ? s : -s, lz = (i & 4) ? s : -s;
+      R ld = nx * lx + ny * ly + nz * lz;
+      R d = zB + ld;
+      if (d < c.margin && ld <= 0 && F.nfb < N_BLOCK_SLOTS) {
+        R r[3] = {lx - nx * d * (R)0.5, ly - ny * d * (R)0.5, lz - nz * d * (R)0.5};
+        R wr[3];
+        cross_(wB, r, wr);
+        R pv[3] = {uB[0] + wr[0], uB[1] + wr[1], uB[2] + wr[2]};
+        R vn = dot_(F.nB, pv), vt1 = dot_(F.t1B, pv), vt2 = dot_(F.t2B, pv);
+        R imp = impedance_(c, d);
+        int sl = SLOT_BLOCK + F.nfb;
+        st.set(sl, 0, r[0]); st.set(sl, 1, r[1]); st.set(sl, 2, r[2]);
+        st.set(sl, 3, -c.B * vn - c.K * imp * (d - c.margin));
+        st.set(sl, 4, -c.B * c.mu * vt1);
+        st.set(sl, 5, -c.B * c.mu * vt2);
+        st.set(sl, 6, imp * rcp_((1 - imp) * c.cD));
+        st.set(sl, 7, (R)meta_make(3, 0, 16));
+        F.nfb++;
+      }
+    }
+  }
+
+  // ---- coupled (block <-> robot) contacts: this project's OWN analytic generator (MuJoCo: mjc_BoxBox / libccd)
+  static BRS_HD R point_box(const R* p, R sx, R sy, R sz, int* axis, R* sign) {
+    R d0 = abs_(p[0]) - sx, d1 = abs_(p[1]) - sy, d2 = abs_(p[2]) - sz;
+    R best = d0; int ax = 0;
+    if (d1 > best) { best = d1; ax = 1; }
+    if (d2 > best) { best = d2; ax = 2; }
+    R pv = ax == 0 ? p[0] : (ax == 1 ? p[1] : p[2]);
+    *axis = ax; *sign = pv >= 0 ? (R)1 : (R)-1;
+    return best;
+  }
+  static BRS_HD void add_coupled(Store<R>& st, Frame& F, const R* rT, const R* nTf, R dist, int sel) {
+    if (F.nc >= N_COUPLED_SLOTS) return;
+    int s = SLOT_COUPLED + F.nc;
+    st.set(s, 0, rT[0]); st.set(s, 1, rT[1]); st.set(s, 2, rT[2]);
+    st.set(s, 3, nTf[0]); st.set(s, 4, nTf[1]); st.set(s, 5, nTf[2]);
+    st.set(s, 6, dist);
+    st.set(s, 7, (R)meta_make(sel, 0, 16));
+    F.nc++;
+  }
+  // everything in the TORSO frame: block centre cB, block axes as columns of RTB = RT^T RB
+  static BRS_HD void collide_coupled(const Params<R>& P, Store<R>& st, Frame& F) {
+    const ContactClass<R>& c = P.cc[CC_BLOCK_ROBOT];
+    R dW[3] = {-F.dTB[0], -F.dTB[1], -F.dTB[2]};  // x_B - x_T (world)
+    R cB[3];
+    mulT_(F.RT, dW, cB);  // block centre in the torso frame
+    R d2 = dot_(cB, cB);
+    R reach = P.torso_brad + P.torso_cz + P.block_brad + c.margin;  // generous: torso geom centre is cz up
+    if (d2 > reach * reach) return;
+    R RTB[9];  // block->torso
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) RTB[3 * i + j] = F.RT[i] * F.RB[j] + F.RT[3 + i] * F.RB[3 + j] + F.RT[6 + i] * F.RB[6 + j];
+    R s = P.block_s;
+    // (i) torso box <-> block box (OWN generator, mirrored in oracle/brs_oracle.c box_box_own): SAT over the 6 face
+    // axes, reference face = minimum overlap, contacts = incident-face vertices behind it and inside its rectangle,
+    // else the deepest incident vertex clamped into the rectangle.  <= 4 points.  No runtime-indexed arrays.
+    R cg[3] = {cB[0], cB[1], cB[2] - P.torso_cz};  // block centre relative to the torso geom centre
+    R dd2 = dot_(cg, cg), rr0 = P.torso_brad + P.block_brad + c.margin;
+    if (dd2 <= rr0 * rr0) {
+      const R sT[3] = {P.torso_sx, P.torso_sy, P.torso_sz};
+      R best = (R)1e30;
+      int bestax = 0;
+      bool sep = false;
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        R ext = s * (abs_(RTB[3 * k]) + abs_(RTB[3 * k + 1]) + abs_(RTB[3 * k + 2]));
+        R ov = sT[k] + ext - abs_(cg[k]);
+        if (ov < -c.margin) sep = true;
+        if (ov < best) { best = ov; bestax = k; }
+      }
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        R dB = cg[0] * RTB[j] + cg[1] * RTB[3 + j] + cg[2] * RTB[6 + j];
+        R ext = sT[0] * abs_(RTB[j]) + sT[1] * abs_(RTB[3 + j]) + sT[2] * abs_(RTB[6 + j]);
+        R ov = s + ext - abs_(dB);
+        if (ov < -c.margin) sep = true;
+        if (ov < best) { best = ov; bestax = 3 + j; }
+      }
+      if (!sep) {
+        int cnt = 0;
+        R fb_dist = (R)1e30, fb_pos[3] = {0, 0, 0}, nrm[3];
+        if (bestax < 3) {
+          const int k = bestax;
+          R sg = pick3(k, cg) >= 0 ? (R)1 : (R)-1;
+          R rk[3] = {pick3(k, RTB[0], RTB[3], RTB[6]), pick3(k, RTB[1], RTB[4], RTB[7]), pick3(k, RTB[2], RTB[5], RTB[8])};
+          int js = 0;
+          if (abs_(rk[1]) > abs_(rk[0])) js = 1;
+          if (abs_(rk[2]) > abs_(pick3(js, rk))) js = 2;
+          R sj = -sg * (pick3(js, rk) >= 0 ? (R)1 : (R)-1);
+          int a1 = js == 2 ? 0 : js + 1;
+#pragma unroll
+          for (int i = 0; i < 3; i++) nrm[i] = i == k ? sg : (R)0;
+          R sTk = pick3(k, sT);
+#pragma unroll
+          for (int v = 0; v < 4; v++) {
+            R loc[3], p[3];
+#pragma unroll
+            for (int i = 0; i < 3; i++) loc[i] = i == js ? sj * s : (((i == a1) ? (v & 1) : (v & 2)) ? s : -s);
+            mul_(RTB, loc, p);
+            p[0] += cg[0]; p[1] += cg[1]; p[2] += cg[2];
+            R dist = sg * pick3(k, p) - sTk;
+            bool lat = true;
+#pragma unroll
+            for (int i = 0; i < 3; i++) lat = lat && (i == k || abs_(p[i]) <= sT[i] + c.margin);
+            if (dist < c.margin && lat) {
+              R pos[3] = {p[0] - nrm[0] * dist * (R)0.5, p[1] - nrm[1] * dist * (R)0.5, p[2] + P.torso_cz - nrm[2] * dist * (R)0.5};
+              add_coupled(st, F, pos, nrm, dist, 0);
+              cnt++;
+            }
+            if (dist < fb_dist) {
+              fb_dist = dist;
+#pragma unroll
+              for (int i = 0; i < 3; i++) fb_pos[i] = i == k ? p[i] : max_(-sT[i], min_(sT[i], p[i]));
+            }
+          }
+          if (cnt == 0 && fb_dist < c.margin) {
+            R pos[3] = {fb_pos[0] - nrm[0] * fb_dist * (R)0.5, fb_pos[1] - nrm[1] * fb_dist * (R)0.5,
+                        fb_pos[2] + P.torso_cz - nrm[2] * fb_dist * (R)0.5};
+            add_coupled(st, F, pos, nrm, fb_dist, 0);
+          }
+        } else {
+          const int j = bestax - 3;
+          R bj[3] = {pick3(j, RTB[0], RTB[1], RTB[2]), pick3(j, RTB[3], RTB[4], RTB[5]), pick3(j, RTB[6], RTB[7], RTB[8])};
+          R dB = dot_(cg, bj), sgB = dB >= 0 ? (R)1 : (R)-1;
+#pragma unroll
+          for (int i = 0; i < 3; i++) nrm[i] = sgB * bj[i];
+          int ks = 0;
+          if (abs_(bj[1]) > abs_(bj[0])) ks = 1;
+          if (abs_(bj[2]) > abs_(pick3(ks, bj))) ks = 2;
+          R sk = sgB * (pick3(ks, bj) >= 0 ? (R)1 : (R)-1);
+          int a1 = ks == 2 ? 0 : ks + 1;
+#pragma unroll
+          for (int v = 0; v < 4; v++) {
+            R loc[3], rel[3], pB[3];
+#pragma unroll
+            for (int i = 0; i < 3; i++) loc[i] = i == ks ? sk * sT[i] : (((i == a1) ? (v & 1) : (v & 2)) ? sT[i] : -sT[i]);
+#pragma unroll
+            for (int i = 0; i < 3; i++) rel[i] = loc[i] - cg[i];
+            mulT_(RTB, rel, pB);
+            R dist = -sgB * pick3(j, pB) - s;
+            bool lat = true;
+#pragma unroll
+            for (int i = 0; i < 3; i++) lat = lat && (i == j || abs_(pB[i]) <= s + c.margin);
+            if (dist < c.margin && lat) {
+              R pos[3] = {loc[0] + nrm[0] * dist * (R)0.5, loc[1] + nrm[1] * dist * (R)0.5, loc[2] + P.torso_cz + nrm[2] * dist * (R)0.5};
+              add_coupled(st, F, pos, nrm, dist, 0);
+              cnt++;
+            }
+            if (dist < fb_dist) {
+              R q[3], back[3];
+#pragma unroll
+              for (int i = 0; i < 3; i++) q[i] = i == j ? pB[i] : max_(-s, min_(s, pB[i]));
+              mul_(RTB, q, back);
+              fb_dist = dist;
+#pragma unroll
+              for (int i = 0; i < 3; i++) fb_pos[i] = back[i] + cg[i];
+            }
+          }
+          if (cnt == 0 && fb_dist < c.margin) {
+            R pos[3] = {fb_pos[0] + nrm[0] * fb_dist * (R)0.5, fb_pos[1] + nrm[1] * fb_dist * (R)0.5,
+                        fb_pos[2] + P.torso_cz + nrm[2] * fb_dist * (R)0.5};
+            add_coupled(st, F, pos, nrm, fb_dist, 0);
+          }
+        }
+      }
+    }
+    // (ii) wheel cylinder <-> block box: single deepest candidate per wheel
+#pragma unroll
+    for (int wsel = 1; wsel <= 2; wsel++) {
+      R wp[3] = {wsel == 1 ? -P.wheel_px : P.wheel_px, (R)0, P.wheel_pz};
+      R d[3] = {cB[0] - wp[0], cB[1] - wp[1], cB[2] - wp[2]};
+      R rr = P.wheel_brad + P.block_brad + c.margin;
+      if (dot_(d, d) > rr * rr) continue;
+      R best = c.margin, bpos[3] = {0, 0, 0}, bn[3] = {0, 0, 1};
+      bool found = false;
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        R loc[3] = {(i & 1) ? s : -s, (i & 2) ? s : -s, (i & 4) ? s : -s}, v[3];
+        mul_(RTB, loc, v);
+        R p[3] = {v[0] + d[0], v[1] + d[1], v[2] + d[2]};  // vertex relative to the wheel centre; axis = x
+        R xi = p[0], rho = sqrt_(p[1] * p[1] + p[2] * p[2]);
+        R drad = rho - P.wheel_r, dax = abs_(xi) - P.wheel_hl, dist, nrm[3];
+        bool ok = true;
+        if (drad >= dax) {
+          if (rho < (R)1e-9) ok = false;
+          R ir = rcp_(max_(rho, (R)1e-9));
+          dist = drad; nrm[0] = 0; nrm[1] = p[1] * ir; nrm[2] = p[2] * ir;
+        } else { dist = dax; nrm[0] = xi >= 0 ? (R)1 : (R)-1; nrm[1] = 0; nrm[2] = 0; }
+        if (ok && dist < best) {
+          best = dist; found = true;
+#pragma unroll
+          for (int j = 0; j < 3; j++) { bn[j] = nrm[j]; bpos[j] = p[j] + wp[j] - nrm[j] * dist * (R)0.5; }
+        }
+      }
+      R xid = d[0], rho = sqrt_(d[1] * d[1] + d[2] * d[2]);
+      if (rho > (R)1e-9) {
+        R ir = rcp_(rho);
+#pragma unroll
+        for (int cand = 0; cand < 2; cand++) {
+          R xc = min_(max_(xid, -P.wheel_hl), P.wheel_hl), rq = P.wheel_r;
+          if (cand == 1) { xc = xid >= 0 ? P.wheel_hl : -P.wheel_hl; rq = min_(rho, P.wheel_r); }
+          R q[3] = {xc, rq * d[1] * ir, rq * d[2] * ir};  // relative to the wheel centre
+          R rel[3] = {q[0] - d[0], q[1] - d[1], q[2] - d[2]}, p[3];
+          mulT_(RTB, rel, p);
+          int ax; R sg;
+          R dist = point_box(p, s, s, s, &ax, &sg);
+          if (dist < best) {
+            best = dist; found = true;
+#pragma unroll
+            for (int j = 0; j < 3; j++) { bn[j] = -sg * RTB[3 * j + ax]; bpos[j] = q[j] + wp[j] + bn[j] * dist * (R)0.5; }
+          }
+        }
+      }
+      if (found) add_coupled(st, F, bpos, bn, best, wsel);
+    }
+  }
+
+  // derived data of one coupled contact (recomputed per pass; coupled contacts are rare)
+  struct Coupled {
+    R rT[3], rB[3], dT[3][3], dB[3][3], wc[3];  // frame axes (n,t1,t2) in torso / block coords
+    R An, Bt1, Bt2, D, mu;
+    int sel;
+  };
+  static BRS_HD void coupled_derive(const Params<R>& P, const Store<R>& st, const Frame& F, const ES& S, int s, Coupled& C) {
+    const ContactClass<R>& c = P.cc[CC_BLOCK_ROBOT];
+    int meta = (int)st.get(s, 7);
+    C.sel = meta_sel(meta);
+    R nTf[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) { C.rT[j] = st.get(s, j); nTf[j] = st.get(s, 3 + j); }
+    R dist = st.get(s, 6);
+    // world frame of the contact: MuJoCo's mju_makeFrame on the world normal
+    R fw[9];
+    mul_(F.RT, nTf, fw);
+    R il = rsqrt_(dot_(fw, fw));
+    fw[0] *= il; fw[1] *= il; fw[2] *= il;
+    fw[3] = 0; fw[4] = 0; fw[5] = 0;
+    if (fw[1] < (R)0.5 && fw[1] > (R)-0.5) fw[4] = 1; else fw[5] = 1;
+    R dp = dot_(fw, fw + 3);
+    fw[3] -= dp * fw[0]; fw[4] -= dp * fw[1]; fw[5] -= dp * fw[2];
+    il = rsqrt_(dot_(fw + 3, fw + 3));
+    fw[3] *= il; fw[4] *= il; fw[5] *= il;
+    cross_(fw, fw + 3, fw + 6);
+    // contact point relative to the block, block frame
+    R pw[3];
+    mul_(F.RT, C.rT, pw);
+    pw[0] += F.dTB[0]; pw[1] += F.dTB[1]; pw[2] += F.dTB[2];
+    mulT_(F.RB, pw, C.rB);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { mulT_(F.RT, fw + 3 * k, C.dT[k]); mulT_(F.RB, fw + 3 * k, C.dB[k]); }
+    wheel_col(P, C.sel, C.rT, C.wc);
+    // relative point velocity (block minus robot) in the contact frame
+    R uT[3], uB[3], t[3];
+    mulT_(F.RT, S.v, uT);
+    mulT_(F.RB, S.bv, uB);
+    cross_(S.w, C.rT, t);
+    R wsel = C.sel == 1 ? S.ww[0] : (C.sel == 2 ? S.ww[1] : (R)0);
+    R pvT[3] = {uT[0] + t[0] + wsel * C.wc[0], uT[1] + t[1] + wsel * C.wc[1], uT[2] + t[2] + wsel * C.wc[2]};
+    cross_(S.bw, C.rB, t);
+    R pvB[3] = {uB[0] + t[0], uB[1] + t[1], uB[2] + t[2]};
+    R vn = dot_(C.dB[0], pvB) - dot_(C.dT[0], pvT), vt1 = dot_(C.dB[1], pvB) - dot_(C.dT[1], pvT),
+      vt2 = dot_(C.dB[2], pvB) - dot_(C.dT[2], pvT);
+    R imp = impedance_(c, dist);
+    C.mu = c.mu;
+    C.An = -c.B * vn - c.K * imp * (dist - c.margin);
+    C.Bt1 = -c.B * c.mu * vt1;
+    C.Bt2 = -c.B * c.mu * vt2;
+    R cD = C.sel == 0 ? c.cD : P.cD_block_wheel;
+    C.D = imp * rcp_((1 - imp) * cD);
+  }
+
+  // ---- pass A: cost, gradient, constraint force and active masks at x
+  static BRS_HD void passA(const Params<R>& P, Store<R>& st, const Frame& F, const ES& S, const R* x, R& cost, R* grad,
+                           R* fcon, bool& same) {
+    R dx[NV], Md[NV];
+#pragma unroll
+    for (int i = 0; i < NV; i++) { dx[i] = x[i] - F.a0[i]; fcon[i] = 0; }
+    mmul_(P, dx, Md);
+    if constexpr (BLK) {
+#pragma unroll
+      for (int i = 0; i < 3; i++) { Md[8 + i] = P.mB * dx[8 + i]; Md[11 + i] = P.IB * dx[11 + i]; }
+    }
+    R cst = 0;
+#pragma unroll
+    for (int i = 0; i < NV; i++) cst += (R)0.5 * dx[i] * Md[i];
+    bool sm = true;
+    // robot <-> floor
+    for (int c = 0; c < F.nfr; c++) {
+      int s = SLOT_ROBOT + c;
+      R r[3] = {st.get(s, 0), st.get(s, 1), st.get(s, 2)};
+      R An = st.get(s, 3), Bt1 = st.get(s, 4), Bt2 = st.get(s, 5), D = st.get(s, 6);
+      int meta = (int)st.get(s, 7), sel = meta_sel(meta);
+      R mu = sel == 0 ? P.cc[CC_TORSO_FLOOR].mu : P.cc[CC_WHEEL_FLOOR].mu;
+      R wc[3], t[3];
+      wheel_col(P, sel, r, wc);
+      cross_(x + 3, r, t);
+      R xs = sel == 1 ? x[6] : (sel == 2 ? x[7] : (R)0);
+      R pa[3] = {x[0] + t[0] + xs * wc[0], x[1] + t[1] + xs * wc[1], x[2] + t[2] + xs * wc[2]};
+      R cn = dot_(F.nT, pa) - An, c1 = mu * dot_(F.t1T, pa) - Bt1, c2 = mu * dot_(F.t2T, pa) - Bt2;
+      R e1 = cn + c1, e2 = cn - c1, e3 = cn + c2, e4 = cn - c2;
+      int mk = (e1 < 0 ? 1 : 0) | (e2 < 0 ? 2 : 0) | (e3 < 0 ? 4 : 0) | (e4 < 0 ? 8 : 0);
+      R l1 = max_(-e1, (R)0), l2 = max_(-e2, (R)0), l3 = max_(-e3, (R)0), l4 = max_(-e4, (R)0);
+      cst += (R)0.5 * D * (l1 * l1 + l2 * l2 + l3 * l3 + l4 * l4);
+      R fn = D * (l1 + l2 + l3 + l4), f1 = D * mu * (l1 - l2), f2 = D * mu * (l3 - l4);
+      R fb[3] = {F.nT[0] * fn + F.t1T[0] * f1 + F.t2T[0] * f2, F.nT[1] * fn + F.t1T[1] * f1 + F.t2T[1] * f2,
+                 F.nT[2] * fn + F.t1T[2] * f1 + F.t2T[2] * f2};
+      cross_(r, fb, t);
+      fcon[0] += fb[0]; fcon[1] += fb[1]; fcon[2] += fb[2];
+      fcon[3] += t[0]; fcon[4] += t[1]; fcon[5] += t[2];
+      R fw = dot_(wc, fb);
+      fcon[6] += sel == 1 ? fw : (R)0;
+      fcon[7] += sel == 2 ? fw : (R)0;
+      if (mk != meta_h(meta)) sm = false;
+      st.set(s, 7, (R)meta_make(sel, mk, meta_h(meta)));
+    }
+    if constexpr (BLK) {
+      for (int c = 0; c < F.nfb; c++) {
+        int s = SLOT_BLOCK + c;
+        R r[3] = {st.get(s, 0), st.get(s, 1), st.get(s, 2)};
+        R An = st.get(s, 3), Bt1 = st.get(s, 4), Bt2 = st.get(s, 5), D = st.get(s, 6);
+        int meta = (int)st.get(s, 7);
+        R mu = P.cc[CC_BLOCK_FLOOR].mu;
+        R t[3];
+        cross_(x + 11, r, t);
+        R pa[3] = {x[8] + t[0], x[9] + t[1], x[10] + t[2]};
+        R cn = dot_(F.nB, pa) - An, c1 = mu * dot_(F.t1B, pa) - Bt1, c2 = mu * dot_(F.t2B, pa) - Bt2;
+        R e1 = cn + c1, e2 = cn - c1, e3 = cn + c2, e4 = cn - c2;
+        int mk = (e1 < 0 ? 1 : 0) | (e2 < 0 ? 2 : 0) | (e3 < 0 ? 4 : 0) | (e4 < 0 ? 8 : 0);
+        R l1 = max_(-e1, (R)0), l2 = max_(-e2, (R)0), l3 = max_(-e3, (R)0), l4 = max_(-e4, (R)0);
+        cst += (R)0.5 * D * (l1 * l1 + l2 * l2 + l3 * l3 + l4 * l4);
+        R fn = D * (l1 + l2 + l3 + l4), f1 = D * mu * (l1 - l2), f2 = D * mu * (l3 - l4);
+        R fb[3] = {F.nB[0] * fn + F.t1B[0] * f1 + F.t2B[0] * f2, F.nB[1] * fn + F.t1B[1] * f1 + F.t2B[1] * f2,
+                   F.nB[2] * fn + F.t1B[2] * f1 + F.t2B[2] * f2};
+        cross_(r, fb, t);
+        fcon[8] += fb[0]; fcon[9] += fb[1]; fcon[10] += fb[2];
+        fcon[11] += t[0]; fcon[12] += t[1]; fcon[13] += t[2];
+        if (mk != meta_h(meta)) sm = false;
+        st.set(s, 7, (R)meta_make(3, mk, meta_h(meta)));
+      }
+      for (int c = 0; c < F.nc; c++) {
+        int s = SLOT_COUPLED + c;
+        Coupled C;
+        coupled_derive(P, st, F, S, s, C);
+        int meta = (int)st.get(s, 7);
+        R t[3];
+        cross_(x + 3, C.rT, t);
+        R xs = C.sel == 1 ? x[6] : (C.sel == 2 ? x[7] : (R)0);
+        R paT[3] = {x[0] + t[0] + xs * C.wc[0], x[1] + t[1] + xs * C.wc[1], x[2] + t[2] + xs * C.wc[2]};
+        cross_(x + 11, C.rB, t);
+        R paB[3] = {x[8] + t[0], x[9] + t[1], x[10] + t[2]};
+        R cn = dot_(C.dB[0], paB) - dot_(C.dT[0], paT) - C.An;
+        R c1 = C.mu * (dot_(C.dB[1], paB) - dot_(C.dT[1], paT)) - C.Bt1;
+        R c2 = C.mu * (dot_(C.dB[2], paB) - dot_(C.dT[2], paT)) - C.Bt2;
+        R e1 = cn + c1, e2 = cn - c1, e3 = cn + c2, e4 = cn - c2;
+        int mk = (e1 < 0 ? 1 : 0) | (e2 < 0 ? 2 : 0) | (e3 < 0 ? 4 : 0) | (e4 < 0 ? 8 : 0);
+        R l1 = max_(-e1, (R)0), l2 = max_(-e2, (R)0), l3 = max_(-e3, (R)0), l4 = max_(-e4, (R)0);
+        cst += (R)0.5 * C.D * (l1 * l1 + l2 * l2 + l3 * l3 + l4 * l4);
+        R fn = C.D * (l1 + l2 + l3 + l4), f1 = C.D * C.mu * (l1 - l2), f2 = C.D * C.mu * (l3 - l4);
+        R fT[3], fB[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          fT[j] = -(C.dT[0][j] * fn + C.dT[1][j] * f1 + C.dT[2][j] * f2);
+          fB[j] = C.dB[0][j] * fn + C.dB[1][j] * f1 + C.dB[2][j] * f2;
+        }
+        cross_(C.rT, fT, t);
+        fcon[0] += fT[0]; fcon[1] += fT[1]; fcon[2] += fT[2];
+        fcon[3] += t[0]; fcon[4] += t[1]; fcon[5] += t[2];
+        R fw = dot_(C.wc, fT);
+        fcon[6] += C.sel == 1 ? fw : (R)0;
+        fcon[7] += C.sel == 2 ? fw : (R)0;
+        cross_(C.rB, fB, t);
+        fcon[8] += fB[0]; fcon[9] += fB[1]; fcon[10] += fB[2];
+        fcon[11] += t[0]; fcon[12] += t[1]; fcon[13] += t[2];
+        if (mk != meta_h(meta)) sm = false;
+        st.set(s, 7, (R)meta_make(C.sel, mk, meta_h(meta)));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; i++) grad[i] = Md[i] - fcon[i];
+    cost = cst;
+    same = sm;
+  }
+
+  // ---- pass B: H = M + sum over active rows D j j^T  (packed lower triangle), then Newton direction
+  static BRS_HD void add_row(R* H, const R* j, R D) {
+#pragma unroll
+    for (int a = 0; a < NV; a++) {
+      R da = D * j[a];
+#pragma unroll
+      for (int b = 0; b <= a; b++) H[tri(a, b)] += da * j[b];
+    }
+  }
+  static BRS_HD void add_row_robot(R* H, const R* j, R D) {
+#pragma unroll
+    for (int a = 0; a < 8; a++) {
+      R da = D * j[a];
+#pragma unroll
+      for (int b = 0; b <= a; b++) H[tri(a, b)] += da * j[b];
+    }
+  }
+  static BRS_HD void add_row_block(R* H, const R* j, R D) {  // j[0..5] -> dofs 8..13
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+      R da = D * j[a];
+#pragma unroll
+      for (int b = 0; b <= a; b++) H[tri(8 + a, 8 + b)] += da * j[b];
+    }
+  }
+
+  static BRS_HD void newton_dir(const Params<R>& P, Store<R>& st, const Frame& F, const ES& S, const R* grad, R* dir) {
+    R H[NH];
+#pragma unroll
+    for (int i = 0; i < NH; i++) H[i] = 0;
+    H[tri(0, 0)] = P.m; H[tri(1, 1)] = P.m; H[tri(2, 2)] = P.m;
+    H[tri(3, 3)] = P.Ixx; H[tri(4, 4)] = P.Iyy; H[tri(5, 5)] = P.Izz; H[tri(6, 6)] = P.Ia; H[tri(7, 7)] = P.Ia;
+    H[tri(4, 0)] = P.mcz; H[tri(3, 1)] = -P.mcz; H[tri(6, 3)] = -P.Ia; H[tri(7, 3)] = P.Ia;
+    if constexpr (BLK) {
+#pragma unroll
+      for (int i = 0; i < 3; i++) { H[tri(8 + i, 8 + i)] = P.mB; H[tri(11 + i, 11 + i)] = P.IB; }
+    }
+    for (int c = 0; c < F.nfr; c++) {
+      int s = SLOT_ROBOT + c;
+      R r[3] = {st.get(s, 0), st.get(s, 1), st.get(s, 2)};
+      R D = st.get(s, 6);
+      int meta = (int)st.get(s, 7), sel = meta_sel(meta), mk = meta_new(meta);
+      st.set(s, 7, (R)meta_make(sel, mk, mk));
+      R mu = sel == 0 ? P.cc[CC_TORSO_FLOOR].mu : P.cc[CC_WHEEL_FLOOR].mu;
+      R wc[3], rn[3], r1[3], r2[3];
+      wheel_col(P, sel, r, wc);
+      cross_(r, F.nT, rn); cross_(r, F.t1T, r1); cross_(r, F.t2T, r2);
+      R wn = dot_(wc, F.nT), w1 = dot_(wc, F.t1T), w2 = dot_(wc, F.t2T);
+      R gn[8] = {F.nT[0], F.nT[1], F.nT[2], rn[0], rn[1], rn[2], sel == 1 ? wn : (R)0, sel == 2 ? wn : (R)0};
+      R g1[8] = {F.t1T[0], F.t1T[1], F.t1T[2], r1[0], r1[1], r1[2], sel == 1 ? w1 : (R)0, sel == 2 ? w1 : (R)0};
+      R g2[8] = {F.t2T[0], F.t2T[1], F.t2T[2], r2[0], r2[1], r2[2], sel == 1 ? w2 : (R)0, sel == 2 ? w2 : (R)0};
+      R j[8];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        R sg = (k & 1) ? -mu : mu;
+#pragma unroll
+        for (int i = 0; i < 8; i++) j[i] = gn[i] + sg * (k < 2 ? g1[i] : g2[i]);
+        add_row_robot(H, j, (mk >> k) & 1 ? D : (R)0);
+      }
+    }
+    bool coupled = false;
+    if constexpr (BLK) {
+      for (int c = 0; c < F.nfb; c++) {
+        int s = SLOT_BLOCK + c;
+        R r[3] = {st.get(s, 0), st.get(s, 1), st.get(s, 2)};
+        R D = st.get(s, 6);
+        int meta = (int)st.get(s, 7), mk = meta_new(meta);
+        st.set(s, 7, (R)meta_make(3, mk, mk));
+        R mu = P.cc[CC_BLOCK_FLOOR].mu;
+        R rn[3], r1[3], r2[3];
+        cross_(r, F.nB, rn); cross_(r, F.t1B, r1); cross_(r, F.t2B, r2);
+        R gn[6] = {F.nB[0], F.nB[1], F.nB[2], rn[0], rn[1], rn[2]};
+        R g1[6] = {F.t1B[0], F.t1B[1], F.t1B[2], r1[0], r1[1], r1[2]};
+        R g2[6] = {F.t2B[0], F.t2B[1], F.t2B[2], r2[0], r2[1], r2[2]};
+        R j[6];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          R sg = (k & 1) ? -mu : mu;
+#pragma unroll
+          for (int i = 0; i < 6; i++) j[i] = gn[i] + sg * (k < 2 ? g1[i] : g2[i]);
+          add_row_block(H, j, (mk >> k) & 1 ? D : (R)0);
+        }
+      }
+      for (int c = 0; c < F.nc; c++) {
+        int s = SLOT_COUPLED + c;
+        Coupled C;
+        coupled_derive(P, st, F, S, s, C);
+        int meta = (int)st.get(s, 7), mk = meta_new(meta);
+        st.set(s, 7, (R)meta_make(C.sel, mk, mk));
+        R g[3][NV];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          R ct[3], cb[3];
+          cross_(C.rT, C.dT[k], ct);
+          cross_(C.rB, C.dB[k], cb);
+          R wk = dot_(C.wc, C.dT[k]);
+#pragma unroll
+          for (int i = 0; i < 3; i++) { g[k][i] = -C.dT[k][i]; g[k][3 + i] = -ct[i]; g[k][8 + i] = C.dB[k][i]; g[k][11 + i] = cb[i]; }
+          g[k][6] = C.sel == 1 ? -wk : (R)0;
+          g[k][7] = C.sel == 2 ? -wk : (R)0;
+        }
+        R j[NV];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          R sg = (k & 1) ? -C.mu : C.mu;
+#pragma unroll
+          for (int i = 0; i < NV; i++) j[i] = g[0][i] + sg * (k < 2 ? g[1][i] : g[2][i]);
+          add_row(H, j, (mk >> k) & 1 ? C.D : (R)0);
+        }
+        coupled = true;
+      }
+    }
+    R ng[NV];
+#pragma unroll
+    for (int i = 0; i < NV; i++) { ng[i] = -grad[i]; dir[i] = 0; }
+    if constexpr (BLK) {
+      if (coupled) chol_solve_block<R, 0, NV>(H, ng, dir);
+      else {
+        chol_solve_block<R, 0, 8>(H, ng, dir);
+        chol_solve_block<R, 8, NV>(H, ng, dir);
+      }
+    } else
+      chol_solve_block<R, 0, 8>(H, ng, dir);
+  }
+
+  // ---- the substep
+  static BRS_HD void substep(const Params<R>& P, Store<R>& st, ES& S, R ctrlL, R ctrlR) {
+    Frame F;
+    // kinematics
+    R qf[4] = {(R)S.q[0], (R)S.q[1], (R)S.q[2], (R)S.q[3]};
+    quat2mat_(qf, F.RT);
+#pragma unroll
+    for (int i = 0; i < 3; i++) { F.nT[i] = F.RT[6 + i]; F.t1T[i] = F.RT[3 + i]; F.t2T[i] = -F.RT[i]; }
+    R u[3];
+    mulT_(F.RT, S.v, u);
+    R zT = (R)(S.p[2] - P.floor_z_d);
+    // smooth forces in body coordinates
+    R wx = S.w[0], wy = S.w[1], wz = S.w[2];
+    R gb[3] = {-P.g * F.nT[0], -P.g * F.nT[1], -P.g * F.nT[2]};
+    R f[8];
+    f[0] = -P.mcz * wx * wz + P.m * gb[0];
+    f[1] = -P.mcz * wy * wz + P.m * gb[1];
+    f[2] = P.mcz * (wx * wx + wy * wy) + P.m * gb[2];
+    R Lx = P.Ixx * wx + P.Ia * (S.ww[1] - S.ww[0]), Ly = P.Iyy * wy, Lz = P.Izz * wz;
+    f[3] = -(wy * Lz - wz * Ly) - P.mcz * gb[1];
+    f[4] = -(wz * Lx - wx * Lz) + P.mcz * gb[0];
+    f[5] = -(wx * Ly - wy * Lx);
+    // velocity servos (envs/robot-02.xml:22-25): ctrl clamp, force clamp; derivative dropped when clamped
+    R uL = min_(max_(ctrlL, -P.ctrlrange), P.ctrlrange), uR = min_(max_(ctrlR, -P.ctrlrange), P.ctrlrange);
+    R fL = P.kv * (uL - S.ww[0]), fR = P.kv * (uR - S.ww[1]);
+    bool clL = fL >= P.forcerange || fL <= -P.forcerange, clR = fR >= P.forcerange || fR <= -P.forcerange;
+    fL = min_(max_(fL, -P.forcerange), P.forcerange);
+    fR = min_(max_(fR, -P.forcerange), P.forcerange);
+    f[6] = fL - P.damping * S.ww[0];
+    f[7] = fR - P.damping * S.ww[1];
+    msolve0_(P, f, F.a0);
+    // collision: robot <-> floor.  Slot priority: wheel main points, torso corners, wheel triangle points
+    F.nfr = 0; F.nfb = 0; F.nc = 0;
+    collide_wheel(P, st, F, u, S.w, S.ww, zT, 1, false);
+    collide_wheel(P, st, F, u, S.w, S.ww, zT, 2, false);
+    collide_torso(P, st, F, u, S.w, S.ww, zT);
+    collide_wheel(P, st, F, u, S.w, S.ww, zT, 1, true);
+    collide_wheel(P, st, F, u, S.w, S.ww, zT, 2, true);
+    R fblk[6];
+    if constexpr (BLK) {
+      R qb[4] = {(R)S.bq[0], (R)S.bq[1], (R)S.bq[2], (R)S.bq[3]};
+      quat2mat_(qb, F.RB);
+#pragma unroll
+      for (int i = 0; i < 3; i++) { F.nB[i] = F.RB[6 + i]; F.t1B[i] = F.RB[3 + i]; F.t2B[i] = -F.RB[i]; }
+      R uB[3];
+      mulT_(F.RB, S.bv, uB);
+      R zB = (R)(S.bp[2] - P.floor_z_d);
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        F.dTB[i] = (R)(S.p[i] - S.bp[i]);
+        fblk[i] = -P.mB * P.g * F.nB[i];
+        fblk[3 + i] = 0;  // isotropic inertia: no gyroscopic torque
+        F.a0[8 + i] = -P.g * F.nB[i];
+        F.a0[11 + i] = 0;
+      }
+      collide_block_floor(P, st, F, uB, S.bw, zB);
+      collide_coupled(P, st, F);
+    }
+    // constraint solve
+    R fcon[NV];
+    if (F.nfr + F.nfb + F.nc == 0) {
+#pragma unroll
+      for (int i = 0; i < NV; i++) { S.a[i] = F.a0[i]; fcon[i] = 0; }
+    } else {
+      R x[NV], grad[NV], cost;
+      bool same;
+#pragma unroll
+      for (int i = 0; i < NV; i++) x[i] = S.a[i];
+      // a body without contacts: its unconstrained acceleration is exact
+      if (F.nc == 0 && F.nfr == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) x[i] = F.a0[i];
+      }
+      if constexpr (BLK) {
+        if (F.nc == 0 && F.nfb == 0) {
+#pragma unroll
+          for (int i = 8; i < NV; i++) x[i] = F.a0[i];
+        }
+      }
+      passA(P, st, F, S, x, cost, grad, fcon, same);
+      for (int it = 0; it < 12; it++) {
+        R dir[NV], xt[NV], gt[NV], ft[NV], ct;
+        bool st_same;
+        newton_dir(P, st, F, S, grad, dir);
+#pragma unroll
+        for (int i = 0; i < NV; i++) xt[i] = x[i] + dir[i];
+        passA(P, st, F, S, xt, ct, gt, ft, st_same);
+        bool full = true;
+        for (int bt = 0; bt < 6 && ct > cost + (R)1e-5 * abs_(cost) + (R)1e-12; bt++) {
+          full = false;
+#pragma unroll
+          for (int i = 0; i < NV; i++) { dir[i] *= (R)0.5; xt[i] = x[i] + dir[i]; }
+          passA(P, st, F, S, xt, ct, gt, ft, st_same);
+        }
+        cost = ct;
+#pragma unroll
+        for (int i = 0; i < NV; i++) { x[i] = xt[i]; grad[i] = gt[i]; fcon[i] = ft[i]; }
+        if (st_same && full) break;
+      }
+#pragma unroll
+      for (int i = 0; i < NV; i++) S.a[i] = x[i];
+    }
+    // implicitfast: (M + h*diag(damping + kv[unclamped])) acc = smooth + constraint
+    R rhs[8], acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) rhs[i] = f[i] + fcon[i];
+    R dL = P.h * (P.damping + (clL ? (R)0 : P.kv)), dR = P.h * (P.damping + (clR ? (R)0 : P.kv));
+    msolve_(P, rhs, dL, dR, acc);
+    // advance: velocities first, then positions with the NEW velocities
+    R aw[3];
+    mul_(F.RT, acc, aw);
+#pragma unroll
+    for (int i = 0; i < 3; i++) { S.v[i] += P.h * aw[i]; S.w[i] += P.h * acc[3 + i]; }
+    S.ww[0] += P.h * acc[6];
+    S.ww[1] += P.h * acc[7];
+#pragma unroll
+    for (int i = 0; i < 3; i++) S.p[i] += P.h_d * (double)S.v[i];
+    quat_advance(S.q, (double)S.w[0], (double)S.w[1], (double)S.w[2], P.h_d);
+    S.th[0] += P.h_d * (double)S.ww[0];
+    S.th[1] += P.h_d * (double)S.ww[1];
+    if constexpr (BLK) {
+      R ab[3], al[3] = {(fblk[0] + fcon[8]) * P.inv_mB, (fblk[1] + fcon[9]) * P.inv_mB, (fblk[2] + fcon[10]) * P.inv_mB};
+      mul_(F.RB, al, ab);
+#pragma unroll
+      for (int i = 0; i < 3; i++) { S.bv[i] += P.h * ab[i]; S.bw[i] += P.h * (fblk[3 + i] + fcon[11 + i]) * P.inv_IB; }
+#pragma unroll
+      for (int i = 0; i < 3; i++) S.bp[i] += P.h_d * (double)S.bv[i];
+      quat_advance(S.bq, (double)S.bw[0], (double)S.bw[1], (double)S.bw[2], P.h_d);
+    }
+    S.time += P.h_d;
+  }
+
+  // =================================================================================== env logic
+  // (restates envs/RobotBaseEnv.py:127-246, env01_v2.py:16-71, env03_v1.py:26-114, env03_v2.py:14-59;
+  //  pinned through oracle/ by tests/golden/envlogic.json)
+  static BRS_HD void pitch_yaw(const double* xq, R& pitch, R& yaw) {
+    if (xq[0] == 0.0) { pitch = 0; yaw = 0; return; }
+    R w = (R)xq[0], x = (R)xq[1], y = (R)xq[2], z = (R)xq[3];
+    R n2 = w * w + x * x + y * y + z * z, s = 2 * rcp_(n2);  // scipy normalises; atan2 is scale-free
+    pitch = atan2_(s * (y * z + w * x), 1 - s * (x * x + y * y));
+    yaw = atan2_(s * (x * y + w * z), 1 - s * (y * y + z * z));
+  }
+  static BRS_HD R get_pitch(const Params<R>& P, const ES& S, Stream<R>& rng) {
+    R p, y;
+    pitch_yaw(S.xq, p, y);
+    if (P.noise) p += (rng.next() - (R)0.5) * (R)0.05;
+    return p;
+  }
+  static BRS_HD R get_reward(const Params<R>& P, const ES& S, Stream<R>& rng) {
+    R dv = (R)0 - (S.ww[0] * (R)-1 + S.ww[1]) / (R)2;
+    R dyd = (R)0 - S.w[2];
+    R pitch = get_pitch(P, S, rng);
+    return (R)1 - (R)0.025 * abs_(dyd) - abs_(pitch) + pitch * dv * (R)0.5;
+  }
+  static BRS_HD void get_obs(const Params<R>& P, ES& S, Stream<R>& rng, bool at_reset, float* obs) {
+    R pitch = get_pitch(P, S, rng);
+    R pitch2 = get_pitch(P, S, rng);
+    R pitch_dot = 0;
+    if (!at_reset) pitch_dot = (pitch2 - S.last_pitch) / ((R)P.nsub * P.h);
+    S.last_pitch = pitch2;
+    R vl = S.ww[0], vr = S.ww[1];
+    R wheel_speed = (vl - vr) / (R)2, wheel_yaw = vl + vr;
+    obs[0] = (float)(pitch / (R)0.25);
+    obs[1] = (float)pitch_dot;
+    obs[2] = (float)(vl / (R)170 * (R)4);
+    obs[3] = (float)(vr / (R)170 * (R)4);
+    obs[4] = (float)(((R)0 - wheel_speed) / (R)170 * (R)4);
+    obs[5] = (float)(((R)0 - wheel_yaw) / (R)45 * (R)3);
+  }
+  // scipy from_euler('xyz',[a,b,c]).as_quat() (x,y,z,w) written unchanged into MuJoCo's (w,x,y,z) slot
+  static BRS_HD void euler_slot_quat(R a, R b, R c, double* q) {
+    R sa, ca, sb, cb, sc, cc;
+    sincos_(a * (R)0.5, &sa, &ca); sincos_(b * (R)0.5, &sb, &cb); sincos_(c * (R)0.5, &sc, &cc);
+    R w = ca * cb * cc + sa * sb * sc, x = sa * cb * cc - ca * sb * sc, y = ca * sb * cc + sa * cb * sc, z = ca * cb * sc - sa * sb * cc;
+    // renormalise in fp64 so the fp64 accumulator starts on the unit sphere
+    double n = 1.0 / sqrt((double)x * x + (double)y * y + (double)z * z + (double)w * w);
+    q[0] = x * n; q[1] = y * n; q[2] = z * n; q[3] = w * n;
+  }
+  static BRS_HD void set_block_pos_vel(const Params<R>& P, ES& S, Stream<R>& rng) {
+    const R TWO_PI = (R)6.283185307179586476925;
+    R ang, tx, tz;
+    R xp0 = (R)S.xp[0], xp1 = (R)S.xp[1];
+    if (P.throw_v2) {
+      R p, yaw;
+      pitch_yaw(S.xq, p, yaw);
+      ang = -yaw;
+      if (!S.side_front) ang += (R)3.14159265358979323846;
+    } else
+      ang = rng.next() * TWO_PI;
+    R sa, ca;
+    sincos_(ang, &sa, &ca);
+    R ox = (R)0.3 * sa, oy = (R)0.3 * ca;  // block position relative to the robot
+    if (P.throw_v2) { tx = (rng.next() - (R)0.5) * (R)0.02; tz = rng.next() * (R)0.025 + (R)0.13; }
+    else { tx = (rng.next() - (R)0.5) * (R)0.06; tz = rng.next() * (R)0.075 + (R)0.1; }
+    R vx = tx - ox, vy = -oy, vz = tz - (R)0.15;
+    R k = P.block_speed * rsqrt_(vx * vx + vy * vy + vz * vz);
+    R xr = rng.next() * TWO_PI, yr = rng.next() * TWO_PI, zr = rng.next() * TWO_PI;
+    S.bp[0] = (double)(ox) + S.xp[0]; S.bp[1] = (double)(oy) + S.xp[1]; S.bp[2] = 0.15;
+    (void)xp0; (void)xp1;
+    euler_slot_quat(xr, yr, zr, S.bq);
+    S.bv[0] = vx * k; S.bv[1] = vy * k; S.bv[2] = vz * k;
+  }
+  static BRS_HD void env_reset(const Params<R>& P, ES& S, Stream<R>& rng, float* obs) {
+    const R TWO_PI = (R)6.283185307179586476925;
+    // MujocoEnv.reset -> mj_resetData ; reset_model: qpos0 + U(-0.01,0.01)^nq, qpos[2] = 0
+    R n[16];
+#pragma unroll
+    for (int i = 0; i < (BLK ? 16 : 9); i++) n[i] = (R)-0.01 + (R)0.02 * rng.next();
+    S.p[0] = n[0]; S.p[1] = n[1]; S.p[2] = 0;
+    S.th[0] = n[7]; S.th[1] = n[8];
+#pragma unroll
+    for (int i = 0; i < 3; i++) { S.v[i] = 0; S.w[i] = 0; }
+    S.ww[0] = S.ww[1] = 0;
+#pragma unroll
+    for (int i = 0; i < NV; i++) S.a[i] = 0;
+    S.time = 0; S.elapsed = 0; S.ep_return = 0;
+    R xr = (rng.next() - (R)0.5) * TWO_PI, yr = (rng.next() - (R)0.5) * P.Sy, zr = (rng.next() - (R)0.5) * P.Sz;
+    euler_slot_quat(xr, yr, zr, S.q);
+#pragma unroll
+    for (int i = 0; i < 4; i++) S.xq[i] = S.q[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) S.xp[i] = S.p[i];
+    if constexpr (BLK) {
+#pragma unroll
+      for (int i = 0; i < 3; i++) { S.bw[i] = 0; }
+      set_block_pos_vel(P, S, rng);
+      S.block_timer = -1.0;
+    }
+    get_obs(P, S, rng, true, obs);
+  }
+
+  // one full env step; obs/terminal_obs are 6 floats
+  static BRS_HD void env_step(const Params<R>& P, Store<R>& st, ES& S, Stream<R>& rng, float a0, float a1, float* obs,
+                              float* terminal_obs, float& reward, int& terminated, int& truncated) {
+    R rew = get_reward(P, S, rng);
+    R ctrlL = S.ww[0] + (R)a0 * (R)4, ctrlR = S.ww[1] + (R)a1 * (R)4;
+    for (int k = 0; k < P.nsub; k++) {
+      if (k == P.nsub - 1) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) S.xq[i] = S.q[i];
+#pragma unroll
+        for (int i = 0; i < 3; i++) S.xp[i] = S.p[i];
+      }
+      substep(P, st, S, ctrlL, ctrlR);
+    }
+    // mj_check*: NaN / runaway -> reset the simulation (counted)
+    bool bad = !(S.p[0] == S.p[0]) || !(S.q[0] == S.q[0]) || !(S.v[0] == S.v[0]) || abs_(S.v[0]) > (R)1e10 ||
+               abs_(S.v[2]) > (R)1e10 || !(S.ww[0] == S.ww[0]);
+    if constexpr (BLK) bad = bad || !(S.bp[0] == S.bp[0]) || !(S.bv[0] == S.bv[0]);
+    if (bad) {
+      float tmp[6];
+      S.bad++;
+      env_reset(P, S, rng, tmp);
+    }
+    if constexpr (BLK) {
+      R bv2 = S.bv[0] * S.bv[0] + S.bv[1] * S.bv[1] + S.bv[2] * S.bv[2];
+      if (bv2 < (R)0.01 && S.block_timer < 0) {
+        S.bp[0] = 10; S.bp[1] = 10; S.bp[2] = 0;
+        S.block_timer = S.time;
+      }
+      if (S.block_timer >= 0 && (S.time - S.block_timer) > P.block_delay) {
+        set_block_pos_vel(P, S, rng);
+        S.block_timer = -1.0;
+      }
+    }
+    terminated = abs_(get_pitch(P, S, rng)) > (R)(50.0 * 3.14159265358979323846 / 180.0) ? 1 : 0;
+    get_obs(P, S, rng, false, obs);
+    S.elapsed++;
+    S.ep_return += rew;
+    truncated = S.elapsed >= P.max_episode_steps ? 1 : 0;
+    reward = (float)rew;
+#pragma unroll
+    for (int i = 0; i < 6; i++) terminal_obs[i] = obs[i];
+    if (P.auto_reset && (terminated || truncated)) env_reset(P, S, rng, obs);
+  }
+};
+
+}  // namespace brs

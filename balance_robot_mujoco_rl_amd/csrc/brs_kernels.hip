@@ -1,0 +1,332 @@
+// brs_kernels.hip -- HIP kernels (gfx950 / CDNA4) and the C ABI of include/brs.h.
+//
+// Kernel design:
+//   * one wavefront LANE per environment instance; a 64-thread workgroup is one wave.  At the benchmark size
+//     (65,536 envs) the grid is 1,024 waves = one wave per SIMD of the 256 CUs, so the register budget is the
+//     full 512 VGPRs and nothing is gained by trading registers for occupancy.
+//   * the whole env step (reward, control law, 250 substeps, block state machine, termination, observation,
+//     time limit, auto-reset with in-kernel Philox) is ONE launch; state is read once from HBM (field-major
+//     SoA: every wave-level load is one contiguous segment) and written once.
+//   * the per-lane contact list lives in LDS as lane-strided columns (word w of slot s at (s*8+w)*64 + lane):
+//     ds_read_b32/ds_write_b32 with consecutive lanes on consecutive banks, conflict-free by construction.
+//   * the tiny dense solves (8x8 / 6x6 / 14x14 Cholesky of M + J^T D J) are fully unrolled on statically
+//     indexed register arrays -- no MFMA (a 2-wheel rigid body is not a dense contraction), no scratch.
+//   * no inter-lane communication, no barriers, no atomics: lanes are independent envs.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/brs.h"
+#include "brs_state.hpp"
+
+using namespace brs;
+
+namespace {
+
+template <bool BLK> constexpr int nslots() { return BLK ? N_SLOTS_ENV03 : N_SLOTS_ENV01; }
+
+template <bool BLK> __device__ __forceinline__ Store<float> lane_store(float* lds) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  return Store<float>{lds + wave * (64 * nslots<BLK>() * SLOT_WORDS) + lane, 64};
+}
+
+template <bool BLK>
+__global__ void __launch_bounds__(256) brs_step_kernel(const Params<float> P, const int N, double* __restrict__ d,
+                                                       float* __restrict__ f, int* __restrict__ ii,
+                                                       const float* __restrict__ actions, float* __restrict__ obs,
+                                                       float* __restrict__ reward, uint8_t* __restrict__ terminated,
+                                                       uint8_t* __restrict__ truncated, float* __restrict__ terminal_obs) {
+  extern __shared__ float lds[];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;  // no barriers anywhere: a partial last wave just masks lanes
+  Store<float> st = lane_store<BLK>(lds);
+  EnvState<float, BLK> S;
+  load_state<float, BLK>(S, d, f, ii, (size_t)N, (size_t)i);
+  Stream<float> rng;
+  rng.open(P.seed, P.gid_base + (int64_t)i, S.rng_ctr);
+  const float a0 = actions[2 * (size_t)i], a1 = actions[2 * (size_t)i + 1];
+  float o[6], to[6], rew;
+  int te, tr;
+  Sim<float, BLK>::env_step(P, st, S, rng, a0, a1, o, to, rew, te, tr);
+  S.rng_ctr = rng.ctr;
+  store_state<float, BLK>(S, d, f, ii, (size_t)N, (size_t)i);
+#pragma unroll
+  for (int k = 0; k < 6; k++) obs[6 * (size_t)i + k] = o[k];
+  if (terminal_obs) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) terminal_obs[6 * (size_t)i + k] = to[k];
+  }
+  reward[i] = rew;
+  terminated[i] = (uint8_t)te;
+  truncated[i] = (uint8_t)tr;
+}
+
+template <bool BLK>
+__global__ void __launch_bounds__(256) brs_reset_kernel(const Params<float> P, const int N, double* __restrict__ d,
+                                                        float* __restrict__ f, int* __restrict__ ii,
+                                                        const uint8_t* __restrict__ mask, float* __restrict__ obs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  if (mask && !mask[i]) return;
+  EnvState<float, BLK> S;
+  load_state<float, BLK>(S, d, f, ii, (size_t)N, (size_t)i);
+  Stream<float> rng;
+  rng.open(P.seed, P.gid_base + (int64_t)i, S.rng_ctr);
+  float o[6];
+  Sim<float, BLK>::env_reset(P, S, rng, o);
+  S.rng_ctr = rng.ctr;
+  store_state<float, BLK>(S, d, f, ii, (size_t)N, (size_t)i);
+#pragma unroll
+  for (int k = 0; k < 6; k++) obs[6 * (size_t)i + k] = o[k];
+}
+
+template <bool BLK>
+__global__ void __launch_bounds__(256) brs_physics_kernel(const Params<float> P, const int N, double* __restrict__ d,
+                                                          float* __restrict__ f, int* __restrict__ ii,
+                                                          const float* __restrict__ ctrl, const int nsub) {
+  extern __shared__ float lds[];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  Store<float> st = lane_store<BLK>(lds);
+  EnvState<float, BLK> S;
+  load_state<float, BLK>(S, d, f, ii, (size_t)N, (size_t)i);
+  const float cl = ctrl[2 * (size_t)i], cr = ctrl[2 * (size_t)i + 1];
+  for (int k = 0; k < nsub; k++) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) S.xq[j] = S.q[j];
+#pragma unroll
+    for (int j = 0; j < 3; j++) S.xp[j] = S.p[j];
+    Sim<float, BLK>::substep(P, st, S, cl, cr);
+  }
+  store_state<float, BLK>(S, d, f, ii, (size_t)N, (size_t)i);
+}
+
+thread_local std::string g_create_error;
+
+}  // namespace
+
+struct brs_handle {
+  Params<float> P;
+  int N = 0, device = 0, bt = 64;
+  bool blk = false;
+  double* d = nullptr;
+  float* f = nullptr;
+  int* ii = nullptr;
+  size_t nd = 0, nf = 0, ni = 0;
+  std::string err;
+};
+
+namespace {
+
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+int fail(brs_handle* h, int code, const std::string& msg) {
+  if (h) h->err = msg; else g_create_error = msg;
+  return code;
+}
+#define BRS_HIP_TRY(h, expr)                                                                              \
+  do {                                                                                                    \
+    hipError_t e_ = (expr);                                                                               \
+    if (e_ != hipSuccess) return fail(h, BRS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+size_t lds_bytes(const brs_handle* h) { return (size_t)h->bt * (h->blk ? N_SLOTS_ENV03 : N_SLOTS_ENV01) * SLOT_WORDS * sizeof(float); }
+int grid_of(const brs_handle* h) { return (h->N + h->bt - 1) / h->bt; }
+
+template <bool BLK> int upload_state(brs_handle* h, const std::vector<double>& d, const std::vector<float>& f, const std::vector<int>& ii) {
+  BRS_HIP_TRY(h, hipMemcpy(h->d, d.data(), d.size() * sizeof(double), hipMemcpyHostToDevice));
+  BRS_HIP_TRY(h, hipMemcpy(h->f, f.data(), f.size() * sizeof(float), hipMemcpyHostToDevice));
+  BRS_HIP_TRY(h, hipMemcpy(h->ii, ii.data(), ii.size() * sizeof(int), hipMemcpyHostToDevice));
+  return BRS_OK;
+}
+int download_state(brs_handle* h, std::vector<double>& d, std::vector<float>& f, std::vector<int>& ii) {
+  d.resize(h->nd); f.resize(h->nf); ii.resize(h->ni);
+  BRS_HIP_TRY(h, hipDeviceSynchronize());
+  BRS_HIP_TRY(h, hipMemcpy(d.data(), h->d, h->nd * sizeof(double), hipMemcpyDeviceToHost));
+  BRS_HIP_TRY(h, hipMemcpy(f.data(), h->f, h->nf * sizeof(float), hipMemcpyDeviceToHost));
+  BRS_HIP_TRY(h, hipMemcpy(ii.data(), h->ii, h->ni * sizeof(int), hipMemcpyDeviceToHost));
+  return BRS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int brs_sizes(int32_t variant, int32_t* nq, int32_t* nv, int32_t* nobs, int32_t* nact) {
+  if (variant < 0 || variant > 3) return BRS_ERR_ARG;
+  bool blk = variant >= 2;
+  if (nq) *nq = blk ? 16 : 9;
+  if (nv) *nv = blk ? 14 : 8;
+  if (nobs) *nobs = 6;
+  if (nact) *nact = 2;
+  return BRS_OK;
+}
+
+int brs_create(const brs_config* cfg, brs_handle** out) {
+  if (!cfg || !out) return fail(nullptr, BRS_ERR_ARG, "brs_create: null argument");
+  *out = nullptr;
+  if (cfg->variant < 0 || cfg->variant > 3) return fail(nullptr, BRS_ERR_ARG, "brs_create: unknown variant");
+  if (cfg->num_envs <= 0) return fail(nullptr, BRS_ERR_ARG, "brs_create: num_envs must be > 0");
+  if ((cfg->flags & BRS_FLAG_NOISE_ON) && (cfg->flags & BRS_FLAG_NOISE_OFF))
+    return fail(nullptr, BRS_ERR_ARG, "brs_create: NOISE_ON and NOISE_OFF are exclusive");
+  int bt = cfg->block_threads > 0 ? cfg->block_threads : 64;
+  if (bt % 64 != 0 || bt > 256) return fail(nullptr, BRS_ERR_ARG, "brs_create: block_threads must be 64, 128, 192 or 256");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return fail(nullptr, BRS_ERR_HIP, std::string("brs_create: no HIP device (") + hipGetErrorString(e) + "); there is no CPU fallback");
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, BRS_ERR_ARG, "brs_create: device ordinal out of range");
+  brs_handle* h = new brs_handle();
+  h->N = cfg->num_envs; h->device = cfg->device; h->bt = bt; h->blk = cfg->variant >= 2;
+  int noise = (cfg->flags & BRS_FLAG_NOISE_ON) ? 1 : ((cfg->flags & BRS_FLAG_NOISE_OFF) ? 0 : -1);
+  h->P = make_params<float>(cfg->variant, cfg->flags & BRS_FLAG_AUTO_RESET, noise, cfg->max_episode_steps, cfg->substeps,
+                            cfg->timestep, cfg->seed, cfg->env_index_base);
+  DeviceGuard g(h->device);
+  size_t N = (size_t)h->N;
+  if (h->blk) { h->nd = Layout<true>::ND * N; h->nf = Layout<true>::NF * N; h->ni = Layout<true>::NI * N; }
+  else { h->nd = Layout<false>::ND * N; h->nf = Layout<false>::NF * N; h->ni = Layout<false>::NI * N; }
+  auto bail = [&](const std::string& m) { std::string mm = m; brs_destroy(h); return fail(nullptr, BRS_ERR_HIP, mm); };
+  if (!g.ok) return bail("brs_create: hipSetDevice failed");
+  if (hipMalloc(&h->d, h->nd * sizeof(double)) != hipSuccess) return bail("brs_create: hipMalloc(fp64 state) failed");
+  if (hipMalloc(&h->f, h->nf * sizeof(float)) != hipSuccess) return bail("brs_create: hipMalloc(fp32 state) failed");
+  if (hipMalloc(&h->ii, h->ni * sizeof(int)) != hipSuccess) return bail("brs_create: hipMalloc(int state) failed");
+  std::vector<double> d(h->nd);
+  std::vector<float> f(h->nf);
+  std::vector<int> ii(h->ni);
+  int rc;
+  if (h->blk) { hostconv::init_state<true>(d.data(), f.data(), ii.data(), N, cfg->seed, cfg->env_index_base); rc = upload_state<true>(h, d, f, ii); }
+  else { hostconv::init_state<false>(d.data(), f.data(), ii.data(), N, cfg->seed, cfg->env_index_base); rc = upload_state<false>(h, d, f, ii); }
+  if (rc != BRS_OK) return bail("brs_create: initial upload failed: " + h->err);
+  // dynamic LDS above the 64 KiB default needs the attribute (Env03, 256-thread blocks: 144 KiB)
+  size_t lb = lds_bytes(h);
+  hipError_t ea = hipSuccess;
+  if (h->blk) {
+    ea = hipFuncSetAttribute((const void*)brs_step_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+    if (ea == hipSuccess) ea = hipFuncSetAttribute((const void*)brs_physics_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+  } else {
+    ea = hipFuncSetAttribute((const void*)brs_step_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+    if (ea == hipSuccess) ea = hipFuncSetAttribute((const void*)brs_physics_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+  }
+  if (ea != hipSuccess) return bail(std::string("brs_create: hipFuncSetAttribute: ") + hipGetErrorString(ea));
+  *out = h;
+  return BRS_OK;
+}
+
+int brs_destroy(brs_handle* h) {
+  if (!h) return BRS_ERR_STATE;
+  {
+    DeviceGuard g(h->device);
+    if (h->d) (void)hipFree(h->d);
+    if (h->f) (void)hipFree(h->f);
+    if (h->ii) (void)hipFree(h->ii);
+  }
+  delete h;
+  return BRS_OK;
+}
+
+const char* brs_last_error(const brs_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int brs_reset(brs_handle* h, const uint8_t* mask_dev, float* obs_dev, void* stream) {
+  if (!h) return BRS_ERR_STATE;
+  if (!obs_dev) return fail(h, BRS_ERR_ARG, "brs_reset: obs_dev is null");
+  DeviceGuard g(h->device);
+  hipStream_t s = (hipStream_t)stream;
+  if (h->blk) hipLaunchKernelGGL(brs_reset_kernel<true>, dim3(grid_of(h)), dim3(h->bt), 0, s, h->P, h->N, h->d, h->f, h->ii, mask_dev, obs_dev);
+  else hipLaunchKernelGGL(brs_reset_kernel<false>, dim3(grid_of(h)), dim3(h->bt), 0, s, h->P, h->N, h->d, h->f, h->ii, mask_dev, obs_dev);
+  BRS_HIP_TRY(h, hipGetLastError());
+  return BRS_OK;
+}
+
+int brs_step(brs_handle* h, const float* actions_dev, float* obs_dev, float* reward_dev, uint8_t* terminated_dev,
+             uint8_t* truncated_dev, float* terminal_obs_dev, void* stream) {
+  if (!h) return BRS_ERR_STATE;
+  if (!actions_dev || !obs_dev || !reward_dev || !terminated_dev || !truncated_dev)
+    return fail(h, BRS_ERR_ARG, "brs_step: null buffer");
+  DeviceGuard g(h->device);
+  hipStream_t s = (hipStream_t)stream;
+  size_t lb = lds_bytes(h);
+  if (h->blk)
+    hipLaunchKernelGGL(brs_step_kernel<true>, dim3(grid_of(h)), dim3(h->bt), lb, s, h->P, h->N, h->d, h->f, h->ii, actions_dev,
+                       obs_dev, reward_dev, terminated_dev, truncated_dev, terminal_obs_dev);
+  else
+    hipLaunchKernelGGL(brs_step_kernel<false>, dim3(grid_of(h)), dim3(h->bt), lb, s, h->P, h->N, h->d, h->f, h->ii, actions_dev,
+                       obs_dev, reward_dev, terminated_dev, truncated_dev, terminal_obs_dev);
+  BRS_HIP_TRY(h, hipGetLastError());
+  return BRS_OK;
+}
+
+int brs_physics(brs_handle* h, const float* ctrl_dev, int32_t nsub, void* stream) {
+  if (!h) return BRS_ERR_STATE;
+  if (!ctrl_dev || nsub < 0) return fail(h, BRS_ERR_ARG, "brs_physics: bad argument");
+  DeviceGuard g(h->device);
+  hipStream_t s = (hipStream_t)stream;
+  size_t lb = lds_bytes(h);
+  if (h->blk) hipLaunchKernelGGL(brs_physics_kernel<true>, dim3(grid_of(h)), dim3(h->bt), lb, s, h->P, h->N, h->d, h->f, h->ii, ctrl_dev, nsub);
+  else hipLaunchKernelGGL(brs_physics_kernel<false>, dim3(grid_of(h)), dim3(h->bt), lb, s, h->P, h->N, h->d, h->f, h->ii, ctrl_dev, nsub);
+  BRS_HIP_TRY(h, hipGetLastError());
+  return BRS_OK;
+}
+
+#define BRS_STATE_ROUNDTRIP(h, MODIFY_T, MODIFY_F, WRITE)                                   \
+  do {                                                                                     \
+    if (!h) return BRS_ERR_STATE;                                                          \
+    DeviceGuard g(h->device);                                                              \
+    std::vector<double> d; std::vector<float> f; std::vector<int> ii;                      \
+    int rc = download_state(h, d, f, ii);                                                  \
+    if (rc != BRS_OK) return rc;                                                           \
+    size_t N = (size_t)h->N; (void)N;                                                      \
+    if (h->blk) { MODIFY_T; } else { MODIFY_F; }                                           \
+    if (WRITE) { rc = h->blk ? upload_state<true>(h, d, f, ii) : upload_state<false>(h, d, f, ii); } \
+    return rc;                                                                             \
+  } while (0)
+
+int brs_get_state(brs_handle* h, double* qpos, double* qvel, double* warm, double* time) {
+  BRS_STATE_ROUNDTRIP(h, hostconv::get_state<true>(d.data(), f.data(), N, qpos, qvel, warm, time),
+                      hostconv::get_state<false>(d.data(), f.data(), N, qpos, qvel, warm, time), false);
+}
+int brs_set_state(brs_handle* h, const double* qpos, const double* qvel, const double* warm, const double* time) {
+  BRS_STATE_ROUNDTRIP(h, hostconv::set_state<true>(d.data(), f.data(), N, qpos, qvel, warm, time),
+                      hostconv::set_state<false>(d.data(), f.data(), N, qpos, qvel, warm, time), true);
+}
+int brs_get_aux(brs_handle* h, double* aux) {
+  if (!aux) return BRS_ERR_ARG;
+  BRS_STATE_ROUNDTRIP(h, hostconv::get_aux<true>(d.data(), f.data(), ii.data(), N, aux),
+                      hostconv::get_aux<false>(d.data(), f.data(), ii.data(), N, aux), false);
+}
+int brs_set_aux(brs_handle* h, const double* aux) {
+  if (!aux) return BRS_ERR_ARG;
+  BRS_STATE_ROUNDTRIP(h, hostconv::set_aux<true>(d.data(), f.data(), ii.data(), N, aux),
+                      hostconv::set_aux<false>(d.data(), f.data(), ii.data(), N, aux), true);
+}
+int brs_get_xpose(brs_handle* h, double* xquat, double* xpos) {
+  BRS_STATE_ROUNDTRIP(h, hostconv::get_xpose<true>(d.data(), N, xquat, xpos), hostconv::get_xpose<false>(d.data(), N, xquat, xpos), false);
+}
+int brs_set_xpose(brs_handle* h, const double* xquat, const double* xpos) {
+  BRS_STATE_ROUNDTRIP(h, hostconv::set_xpose<true>(d.data(), N, xquat, xpos), hostconv::set_xpose<false>(d.data(), N, xquat, xpos), true);
+}
+
+int64_t brs_step_bytes_per_env(const brs_handle* h) {
+  if (!h) return 0;
+  size_t st = h->blk ? Layout<true>::bytes_per_env : Layout<false>::bytes_per_env;
+  // state read + state written + action (8) + obs (24) + terminal obs (24) + reward (4) + two flags (2)
+  return (int64_t)(2 * st + 8 + 24 + 24 + 4 + 2);
+}
+const char* brs_step_kernel_name(const brs_handle* h) {
+  if (!h) return "";
+  return h->blk ? "brs_step_kernel<true>" : "brs_step_kernel<false>";
+}
+
+}  // extern "C"

@@ -1,0 +1,258 @@
+// brs_state.hpp -- persistent per-env state in HBM: struct-of-arrays, field-major ([field][N]) so that
+// lane i of a wavefront reads element i of every field: each wave-level load is one contiguous
+// 512 B (fp64) / 256 B (fp32) segment.  Positions/quaternions/time are fp64 accumulators (h = 2e-5 makes
+// per-substep increments ~1e-5 of the value); velocities, warm start and env scalars are fp32.
+//
+// Also: conversion between this layout and MuJoCo-style row-major (qpos[N][nq], qvel[N][nv],
+// qacc_warmstart[N][nv], time[N]) used by brs_get_state / brs_set_state (host side, fp64).
+#pragma once
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+
+#include "brs_core.hpp"
+
+namespace brs {
+
+template <bool BLK> struct Layout {
+  static constexpr int NQ = BLK ? 16 : 9, NV = BLK ? 14 : 8;
+  // fp64 fields
+  static constexpr int D_P = 0, D_Q = 3, D_TH = 7, D_TIME = 9, D_XQ = 10, D_XP = 14, D_BP = 17, D_BQ = 20, D_TIMER = 24;
+  static constexpr int ND = BLK ? 25 : 17;
+  // fp32 fields
+  static constexpr int F_V = 0, F_W = 3, F_WW = 6, F_A = 8, F_LASTPITCH = 8 + NV, F_EPRET = 9 + NV, F_BV = 10 + NV,
+                       F_BW = 13 + NV;
+  static constexpr int NF = BLK ? 16 + NV : 10 + NV;
+  // int32 fields
+  static constexpr int I_ELAPSED = 0, I_RNG = 1, I_SIDE = 2, I_BAD = 3, NI = 4;
+  static constexpr size_t bytes_per_env = (size_t)ND * 8 + (size_t)NF * 4 + (size_t)NI * 4;
+};
+
+template <typename R, bool BLK, typename FT>
+BRS_HD void load_state(EnvState<R, BLK>& S, const double* d, const FT* f, const int* ii, size_t N, size_t i) {
+  using L = Layout<BLK>;
+#pragma unroll
+  for (int k = 0; k < 3; k++) { S.p[k] = d[(L::D_P + k) * N + i]; S.xp[k] = d[(L::D_XP + k) * N + i]; }
+#pragma unroll
+  for (int k = 0; k < 4; k++) { S.q[k] = d[(L::D_Q + k) * N + i]; S.xq[k] = d[(L::D_XQ + k) * N + i]; }
+  S.th[0] = d[(L::D_TH + 0) * N + i]; S.th[1] = d[(L::D_TH + 1) * N + i];
+  S.time = d[L::D_TIME * N + i];
+#pragma unroll
+  for (int k = 0; k < 3; k++) { S.v[k] = (R)f[(L::F_V + k) * N + i]; S.w[k] = (R)f[(L::F_W + k) * N + i]; }
+  S.ww[0] = (R)f[(L::F_WW + 0) * N + i]; S.ww[1] = (R)f[(L::F_WW + 1) * N + i];
+#pragma unroll
+  for (int k = 0; k < L::NV; k++) S.a[k] = (R)f[(L::F_A + k) * N + i];
+  S.last_pitch = (R)f[L::F_LASTPITCH * N + i];
+  S.ep_return = (R)f[L::F_EPRET * N + i];
+  if constexpr (BLK) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      S.bp[k] = d[(L::D_BP + k) * N + i];
+      S.bv[k] = (R)f[(L::F_BV + k) * N + i];
+      S.bw[k] = (R)f[(L::F_BW + k) * N + i];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) S.bq[k] = d[(L::D_BQ + k) * N + i];
+    S.block_timer = d[L::D_TIMER * N + i];
+  } else
+    S.block_timer = -1.0;
+  S.elapsed = ii[L::I_ELAPSED * N + i];
+  S.rng_ctr = (uint32_t)ii[L::I_RNG * N + i];
+  S.side_front = ii[L::I_SIDE * N + i];
+  S.bad = ii[L::I_BAD * N + i];
+}
+
+template <typename R, bool BLK, typename FT>
+BRS_HD void store_state(const EnvState<R, BLK>& S, double* d, FT* f, int* ii, size_t N, size_t i) {
+  using L = Layout<BLK>;
+#pragma unroll
+  for (int k = 0; k < 3; k++) { d[(L::D_P + k) * N + i] = S.p[k]; d[(L::D_XP + k) * N + i] = S.xp[k]; }
+#pragma unroll
+  for (int k = 0; k < 4; k++) { d[(L::D_Q + k) * N + i] = S.q[k]; d[(L::D_XQ + k) * N + i] = S.xq[k]; }
+  d[(L::D_TH + 0) * N + i] = S.th[0]; d[(L::D_TH + 1) * N + i] = S.th[1];
+  d[L::D_TIME * N + i] = S.time;
+#pragma unroll
+  for (int k = 0; k < 3; k++) { f[(L::F_V + k) * N + i] = (FT)S.v[k]; f[(L::F_W + k) * N + i] = (FT)S.w[k]; }
+  f[(L::F_WW + 0) * N + i] = (FT)S.ww[0]; f[(L::F_WW + 1) * N + i] = (FT)S.ww[1];
+#pragma unroll
+  for (int k = 0; k < L::NV; k++) f[(L::F_A + k) * N + i] = (FT)S.a[k];
+  f[L::F_LASTPITCH * N + i] = (FT)S.last_pitch;
+  f[L::F_EPRET * N + i] = (FT)S.ep_return;
+  if constexpr (BLK) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      d[(L::D_BP + k) * N + i] = S.bp[k];
+      f[(L::F_BV + k) * N + i] = (FT)S.bv[k];
+      f[(L::F_BW + k) * N + i] = (FT)S.bw[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) d[(L::D_BQ + k) * N + i] = S.bq[k];
+    d[L::D_TIMER * N + i] = S.block_timer;
+  }
+  ii[L::I_ELAPSED * N + i] = S.elapsed;
+  ii[L::I_RNG * N + i] = (int)S.rng_ctr;
+  ii[L::I_SIDE * N + i] = S.side_front;
+  ii[L::I_BAD * N + i] = S.bad;
+}
+
+// ---------------------------------------------------------------------------------- host conversions (fp64)
+namespace hostconv {
+
+inline void quat_norm(double* q) {
+  double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  if (n < 1e-15) { q[0] = 1; q[1] = q[2] = q[3] = 0; return; }
+  for (int k = 0; k < 4; k++) q[k] /= n;
+}
+inline void quat_mat(const double* q, double* M) { quat2mat_<double>(q, M); }
+
+// fresh envs: qpos0, zero velocity, accessor pose = identity, RNG block 0 reserved for the per-env "side" draw
+template <bool BLK, typename FT>
+inline void init_state(double* d, FT* f, int* ii, size_t N, uint64_t seed, int64_t gid_base) {
+  using L = Layout<BLK>;
+  for (size_t k = 0; k < (size_t)L::ND * N; k++) d[k] = 0;
+  for (size_t k = 0; k < (size_t)L::NF * N; k++) f[k] = 0;
+  for (size_t k = 0; k < (size_t)L::NI * N; k++) ii[k] = 0;
+  for (size_t i = 0; i < N; i++) {
+    d[(L::D_Q + 0) * N + i] = 1; d[(L::D_XQ + 0) * N + i] = 1;
+    if (BLK) { d[(L::D_BQ + 0) * N + i] = 1; d[L::D_TIMER * N + i] = -1.0; }
+    uint32_t o[4];
+    int64_t gid = gid_base + (int64_t)i;
+    philox4x32_10(0u, 0u, (uint32_t)((uint64_t)gid & 0xffffffffu), (uint32_t)((uint64_t)gid >> 32),
+                  (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), o);
+    double u0 = (double)(o[0] >> 8) * (1.0 / 16777216.0);
+    ii[L::I_SIDE * N + i] = u0 > 0.5 ? 1 : 0;  // Env03_v2.__init__ (envs/env03_v2.py:22)
+    ii[L::I_RNG * N + i] = 1;
+  }
+}
+
+// MuJoCo-style rows -> SoA.  Any of qpos/qvel/warm/time may be null (left untouched).  Setting qpos also
+// refreshes the accessor pose (what set_state's mj_forward does) and normalises the quaternions.
+template <bool BLK, typename FT>
+inline void set_state(double* d, FT* f, size_t N, const double* qpos, const double* qvel, const double* warm,
+                      const double* time) {
+  using L = Layout<BLK>;
+  for (size_t i = 0; i < N; i++) {
+    if (qpos) {
+      const double* q = qpos + i * L::NQ;
+      double qt[4] = {q[3], q[4], q[5], q[6]};
+      quat_norm(qt);
+      for (int k = 0; k < 3; k++) { d[(L::D_P + k) * N + i] = q[k]; d[(L::D_XP + k) * N + i] = q[k]; }
+      for (int k = 0; k < 4; k++) { d[(L::D_Q + k) * N + i] = qt[k]; d[(L::D_XQ + k) * N + i] = qt[k]; }
+      d[(L::D_TH + 0) * N + i] = q[7]; d[(L::D_TH + 1) * N + i] = q[8];
+      if (BLK) {
+        double qb[4] = {q[12], q[13], q[14], q[15]};
+        quat_norm(qb);
+        for (int k = 0; k < 3; k++) d[(L::D_BP + k) * N + i] = q[9 + k];
+        for (int k = 0; k < 4; k++) d[(L::D_BQ + k) * N + i] = qb[k];
+      }
+    }
+    if (qvel) {
+      const double* v = qvel + i * L::NV;
+      for (int k = 0; k < 3; k++) { f[(L::F_V + k) * N + i] = (FT)v[k]; f[(L::F_W + k) * N + i] = (FT)v[3 + k]; }
+      f[(L::F_WW + 0) * N + i] = (FT)v[6]; f[(L::F_WW + 1) * N + i] = (FT)v[7];
+      if (BLK)
+        for (int k = 0; k < 3; k++) { f[(L::F_BV + k) * N + i] = (FT)v[8 + k]; f[(L::F_BW + k) * N + i] = (FT)v[11 + k]; }
+    }
+    if (warm) {  // world-frame linear accelerations -> body-frame linear coordinates of the solver variable
+      const double* a = warm + i * L::NV;
+      double qt[4], M[9];
+      for (int k = 0; k < 4; k++) qt[k] = d[(L::D_Q + k) * N + i];
+      quat_mat(qt, M);
+      for (int k = 0; k < 3; k++) f[(L::F_A + k) * N + i] = (FT)(M[k] * a[0] + M[3 + k] * a[1] + M[6 + k] * a[2]);
+      for (int k = 3; k < 8; k++) f[(L::F_A + k) * N + i] = (FT)a[k];
+      if (BLK) {
+        for (int k = 0; k < 4; k++) qt[k] = d[(L::D_BQ + k) * N + i];
+        quat_mat(qt, M);
+        for (int k = 0; k < 3; k++) f[(L::F_A + 8 + k) * N + i] = (FT)(M[k] * a[8] + M[3 + k] * a[9] + M[6 + k] * a[10]);
+        for (int k = 11; k < 14; k++) f[(L::F_A + k) * N + i] = (FT)a[k];
+      }
+    }
+    if (time) d[L::D_TIME * N + i] = time[i];
+  }
+}
+
+template <bool BLK, typename FT>
+inline void get_state(const double* d, const FT* f, size_t N, double* qpos, double* qvel, double* warm, double* time) {
+  using L = Layout<BLK>;
+  for (size_t i = 0; i < N; i++) {
+    if (qpos) {
+      double* q = qpos + i * L::NQ;
+      for (int k = 0; k < 3; k++) q[k] = d[(L::D_P + k) * N + i];
+      for (int k = 0; k < 4; k++) q[3 + k] = d[(L::D_Q + k) * N + i];
+      q[7] = d[(L::D_TH + 0) * N + i]; q[8] = d[(L::D_TH + 1) * N + i];
+      if (BLK) {
+        for (int k = 0; k < 3; k++) q[9 + k] = d[(L::D_BP + k) * N + i];
+        for (int k = 0; k < 4; k++) q[12 + k] = d[(L::D_BQ + k) * N + i];
+      }
+    }
+    if (qvel) {
+      double* v = qvel + i * L::NV;
+      for (int k = 0; k < 3; k++) { v[k] = f[(L::F_V + k) * N + i]; v[3 + k] = f[(L::F_W + k) * N + i]; }
+      v[6] = f[(L::F_WW + 0) * N + i]; v[7] = f[(L::F_WW + 1) * N + i];
+      if (BLK)
+        for (int k = 0; k < 3; k++) { v[8 + k] = f[(L::F_BV + k) * N + i]; v[11 + k] = f[(L::F_BW + k) * N + i]; }
+    }
+    if (warm) {
+      double* a = warm + i * L::NV;
+      double qt[4], M[9], ab[3];
+      for (int k = 0; k < 4; k++) qt[k] = d[(L::D_XQ + k) * N + i];  // frame of the last forward pass
+      quat_mat(qt, M);
+      for (int k = 0; k < 3; k++) ab[k] = f[(L::F_A + k) * N + i];
+      for (int k = 0; k < 3; k++) a[k] = M[3 * k] * ab[0] + M[3 * k + 1] * ab[1] + M[3 * k + 2] * ab[2];
+      for (int k = 3; k < 8; k++) a[k] = f[(L::F_A + k) * N + i];
+      if (BLK) {
+        for (int k = 0; k < 4; k++) qt[k] = d[(L::D_BQ + k) * N + i];
+        quat_mat(qt, M);
+        for (int k = 0; k < 3; k++) ab[k] = f[(L::F_A + 8 + k) * N + i];
+        for (int k = 0; k < 3; k++) a[8 + k] = M[3 * k] * ab[0] + M[3 * k + 1] * ab[1] + M[3 * k + 2] * ab[2];
+        for (int k = 11; k < 14; k++) a[k] = f[(L::F_A + k) * N + i];
+      }
+    }
+    if (time) time[i] = d[L::D_TIME * N + i];
+  }
+}
+
+// aux rows [N][10]: last_pitch, block_timer (NaN = None), elapsed, rng_ctr, side_front, accessor pitch (read-only),
+//                   ep_return, bad count, (2 unused)
+template <bool BLK, typename FT> inline void get_aux(const double* d, const FT* f, const int* ii, size_t N, double* aux) {
+  using L = Layout<BLK>;
+  for (size_t i = 0; i < N; i++) {
+    double* a = aux + 10 * i;
+    a[0] = f[L::F_LASTPITCH * N + i];
+    double t = BLK ? d[L::D_TIMER * N + i] : -1.0;
+    a[1] = t < 0 ? std::nan("") : t;
+    a[2] = ii[L::I_ELAPSED * N + i]; a[3] = (uint32_t)ii[L::I_RNG * N + i]; a[4] = ii[L::I_SIDE * N + i];
+    double xq[4];
+    for (int k = 0; k < 4; k++) xq[k] = d[(L::D_XQ + k) * N + i];
+    double p, y;
+    Sim<double, BLK>::pitch_yaw(xq, p, y);
+    a[5] = p; a[6] = f[L::F_EPRET * N + i]; a[7] = ii[L::I_BAD * N + i]; a[8] = a[9] = 0;
+  }
+}
+template <bool BLK, typename FT> inline void set_aux(double* d, FT* f, int* ii, size_t N, const double* aux) {
+  using L = Layout<BLK>;
+  for (size_t i = 0; i < N; i++) {
+    const double* a = aux + 10 * i;
+    f[L::F_LASTPITCH * N + i] = (FT)a[0];
+    if (BLK) d[L::D_TIMER * N + i] = (a[1] != a[1]) ? -1.0 : a[1];
+    ii[L::I_ELAPSED * N + i] = (int)a[2]; ii[L::I_RNG * N + i] = (int)(uint32_t)a[3]; ii[L::I_SIDE * N + i] = a[4] != 0;
+    f[L::F_EPRET * N + i] = (FT)a[6];
+  }
+}
+template <bool BLK> inline void get_xpose(const double* d, size_t N, double* xq, double* xp) {
+  using L = Layout<BLK>;
+  for (size_t i = 0; i < N; i++) {
+    if (xq) for (int k = 0; k < 4; k++) xq[4 * i + k] = d[(L::D_XQ + k) * N + i];
+    if (xp) for (int k = 0; k < 3; k++) xp[3 * i + k] = d[(L::D_XP + k) * N + i];
+  }
+}
+template <bool BLK> inline void set_xpose(double* d, size_t N, const double* xq, const double* xp) {
+  using L = Layout<BLK>;
+  for (size_t i = 0; i < N; i++) {
+    if (xq) for (int k = 0; k < 4; k++) d[(L::D_XQ + k) * N + i] = xq[4 * i + k];
+    if (xp) for (int k = 0; k < 3; k++) d[(L::D_XP + k) * N + i] = xp[3 * i + k];
+  }
+}
+
+}  // namespace hostconv
+}  // namespace brs

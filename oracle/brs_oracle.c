@@ -415,42 +415,108 @@ static double point_box(const double* p, const double* s, int* axis, double* sig
   return best;
 }
 
-/* OWN generator (not MuJoCo's mjc_BoxBox): vertex-in-box contacts both ways; geom1 = torso, geom2 = block */
+/* OWN generator (not MuJoCo's mjc_BoxBox): separating-axis test over the 6 face axes, reference face = axis of
+ * minimum overlap, contacts = vertices of the other box's incident face that lie behind the reference face
+ * (dist < margin) and inside its rectangle (+margin); if none qualifies, the deepest incident vertex clamped into
+ * the rectangle.  At most 4 points.  geom1 = torso, geom2 = block, normal from torso to block.
+ * Worked in the torso-geom frame, as the HIP kernel does. */
 static void box_box_own(const model_t* m, const double* tpos, const double* tmat, const double* bpos, const double* bmat,
                         const cparam* cp, bo_contact* con, int* n) {
-  double d[3] = {bpos[0] - tpos[0], bpos[1] - tpos[1], bpos[2] - tpos[2]};
-  double rt = norm3(m->torso_size), rb = norm3(m->block_size);
-  if (norm3(d) > rt + rb + cp->margin) return;
-  int cnt = 0;
-  for (int i = 0; i < 8 && cnt < 8; i++) { /* block vertices inside the torso box */
-    double loc[3] = {(i & 1) ? m->block_size[0] : -m->block_size[0], (i & 2) ? m->block_size[1] : -m->block_size[1],
-                     (i & 4) ? m->block_size[2] : -m->block_size[2]}, v[3], p[3], sg;
-    mulMatVec3(v, bmat, loc);
-    for (int j = 0; j < 3; j++) v[j] += bpos[j];
-    double rel[3] = {v[0] - tpos[0], v[1] - tpos[1], v[2] - tpos[2]};
-    mulMatTVec3(p, tmat, rel);
-    int ax;
-    double dist = point_box(p, m->torso_size, &ax, &sg);
-    if (dist >= cp->margin) continue;
-    double nrm[3] = {sg * tmat[ax], sg * tmat[3 + ax], sg * tmat[6 + ax]}, pos[3];
-    for (int j = 0; j < 3; j++) pos[j] = v[j] - nrm[j] * dist * 0.5;
-    add_contact(con, n, dist, pos, nrm, B_TORSO, B_BLOCK, cp);
-    cnt++;
+  double dw[3] = {bpos[0] - tpos[0], bpos[1] - tpos[1], bpos[2] - tpos[2]}, cg[3], RTB[9];
+  double rt = norm3(m->torso_size), rb = norm3(m->block_size), margin = cp->margin;
+  if (norm3(dw) > rt + rb + margin) return;
+  mulMatTVec3(cg, tmat, dw);
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) RTB[3 * i + j] = tmat[i] * bmat[j] + tmat[3 + i] * bmat[3 + j] + tmat[6 + i] * bmat[6 + j];
+  const double* sT = m->torso_size;
+  double s = m->block_size[0];
+  double best = 1e30;
+  int bestax = -1;
+  for (int k = 0; k < 3; k++) { /* torso face axes */
+    double ext = s * (fabs(RTB[3 * k]) + fabs(RTB[3 * k + 1]) + fabs(RTB[3 * k + 2]));
+    double ov = sT[k] + ext - fabs(cg[k]);
+    if (ov < -margin) return;
+    if (ov < best) { best = ov; bestax = k; }
   }
-  for (int i = 0; i < 8 && cnt < 8; i++) { /* torso vertices inside the block */
-    double loc[3] = {(i & 1) ? m->torso_size[0] : -m->torso_size[0], (i & 2) ? m->torso_size[1] : -m->torso_size[1],
-                     (i & 4) ? m->torso_size[2] : -m->torso_size[2]}, v[3], p[3], sg;
-    mulMatVec3(v, tmat, loc);
-    for (int j = 0; j < 3; j++) v[j] += tpos[j];
-    double rel[3] = {v[0] - bpos[0], v[1] - bpos[1], v[2] - bpos[2]};
-    mulMatTVec3(p, bmat, rel);
-    int ax;
-    double dist = point_box(p, m->block_size, &ax, &sg);
-    if (dist >= cp->margin) continue;
-    double nrm[3] = {-sg * bmat[ax], -sg * bmat[3 + ax], -sg * bmat[6 + ax]}, pos[3]; /* from torso towards block */
-    for (int j = 0; j < 3; j++) pos[j] = v[j] + nrm[j] * dist * 0.5;
-    add_contact(con, n, dist, pos, nrm, B_TORSO, B_BLOCK, cp);
-    cnt++;
+  for (int j = 0; j < 3; j++) { /* block face axes */
+    double dB = cg[0] * RTB[j] + cg[1] * RTB[3 + j] + cg[2] * RTB[6 + j];
+    double ext = sT[0] * fabs(RTB[j]) + sT[1] * fabs(RTB[3 + j]) + sT[2] * fabs(RTB[6 + j]);
+    double ov = s + ext - fabs(dB);
+    if (ov < -margin) return;
+    if (ov < best) { best = ov; bestax = 3 + j; }
+  }
+  double cpos[4][3], cdist[4], nT[3];
+  int cnt = 0;
+  double fb_dist = 1e30, fb_pos[3] = {0, 0, 0};
+  if (bestax < 3) {
+    int k = bestax, j1 = (k + 1) % 3, j2 = (k + 2) % 3;
+    double sg = cg[k] >= 0 ? 1.0 : -1.0;
+    nT[0] = nT[1] = nT[2] = 0; nT[k] = sg;
+    int js = 0; /* block axis most aligned with the reference normal */
+    for (int j = 1; j < 3; j++) if (fabs(RTB[3 * k + j]) > fabs(RTB[3 * k + js])) js = j;
+    double sj = -sg * (RTB[3 * k + js] >= 0 ? 1.0 : -1.0);
+    int a1 = (js + 1) % 3, a2 = (js + 2) % 3;
+    for (int v = 0; v < 4; v++) {
+      double loc[3], p[3];
+      loc[js] = sj * s; loc[a1] = (v & 1) ? s : -s; loc[a2] = (v & 2) ? s : -s;
+      mulMatVec3(p, RTB, loc);
+      for (int i = 0; i < 3; i++) p[i] += cg[i];
+      double dist = sg * p[k] - sT[k];
+      int lat = fabs(p[j1]) <= sT[j1] + margin && fabs(p[j2]) <= sT[j2] + margin;
+      if (dist < margin && lat) {
+        for (int i = 0; i < 3; i++) cpos[cnt][i] = p[i] - nT[i] * dist * 0.5;
+        cdist[cnt++] = dist;
+      }
+      if (dist < fb_dist) {
+        fb_dist = dist;
+        for (int i = 0; i < 3; i++) fb_pos[i] = p[i];
+        fb_pos[j1] = fmax(-sT[j1], fmin(sT[j1], fb_pos[j1]));
+        fb_pos[j2] = fmax(-sT[j2], fmin(sT[j2], fb_pos[j2]));
+      }
+    }
+    if (cnt == 0 && fb_dist < margin) {
+      for (int i = 0; i < 3; i++) cpos[0][i] = fb_pos[i] - nT[i] * fb_dist * 0.5;
+      cdist[0] = fb_dist; cnt = 1;
+    }
+  } else {
+    int j = bestax - 3, i1 = (j + 1) % 3, i2 = (j + 2) % 3;
+    double bj[3] = {RTB[j], RTB[3 + j], RTB[6 + j]};
+    double dB = dot3(cg, bj), sgB = dB >= 0 ? 1.0 : -1.0;
+    for (int i = 0; i < 3; i++) nT[i] = sgB * bj[i];
+    int ks = 0; /* torso axis most aligned with the reference normal */
+    for (int k = 1; k < 3; k++) if (fabs(bj[k]) > fabs(bj[ks])) ks = k;
+    double sk = sgB * (bj[ks] >= 0 ? 1.0 : -1.0);
+    int a1 = (ks + 1) % 3, a2 = (ks + 2) % 3;
+    for (int v = 0; v < 4; v++) {
+      double loc[3], rel[3], pB[3];
+      loc[ks] = sk * sT[ks]; loc[a1] = (v & 1) ? sT[a1] : -sT[a1]; loc[a2] = (v & 2) ? sT[a2] : -sT[a2];
+      for (int i = 0; i < 3; i++) rel[i] = loc[i] - cg[i];
+      mulMatTVec3(pB, RTB, rel);
+      double dist = -sgB * pB[j] - s;
+      int lat = fabs(pB[i1]) <= s + margin && fabs(pB[i2]) <= s + margin;
+      if (dist < margin && lat) {
+        for (int i = 0; i < 3; i++) cpos[cnt][i] = loc[i] + nT[i] * dist * 0.5;
+        cdist[cnt++] = dist;
+      }
+      if (dist < fb_dist) {
+        double q[3] = {pB[0], pB[1], pB[2]}, back[3];
+        q[i1] = fmax(-s, fmin(s, q[i1])); q[i2] = fmax(-s, fmin(s, q[i2]));
+        mulMatVec3(back, RTB, q);
+        fb_dist = dist;
+        for (int i = 0; i < 3; i++) fb_pos[i] = back[i] + cg[i];
+      }
+    }
+    if (cnt == 0 && fb_dist < margin) {
+      for (int i = 0; i < 3; i++) cpos[0][i] = fb_pos[i] + nT[i] * fb_dist * 0.5;
+      cdist[0] = fb_dist; cnt = 1;
+    }
+  }
+  for (int c = 0; c < cnt; c++) {
+    double pw[3], nw[3];
+    mulMatVec3(pw, tmat, cpos[c]);
+    mulMatVec3(nw, tmat, nT);
+    for (int i = 0; i < 3; i++) pw[i] += tpos[i];
+    add_contact(con, n, cdist[c], pw, nw, B_TORSO, B_BLOCK, cp);
   }
 }
 

@@ -1,0 +1,144 @@
+// hostsim.cpp -- HOST compilation of the kernel source (balance_robot_mujoco_rl_amd/csrc/brs_core.hpp) for tests.
+// TEST INFRASTRUCTURE ONLY: lets the CPU test-suite check the fp32 algorithm the HIP kernel runs (and a
+// double instantiation of the same closed forms) against oracle/ without a GPU.  Never loaded by the
+// product; the product path is libbrs_hip.so and fails loudly without a GPU.
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "brs_state.hpp"
+
+using namespace brs;
+
+struct IHost {
+  virtual ~IHost() {}
+  virtual int nq() const = 0;
+  virtual int nv() const = 0;
+  virtual void set_state(const double*, const double*, const double*, const double*) = 0;
+  virtual void get_state(double*, double*, double*, double*) const = 0;
+  virtual void get_aux(double*) const = 0;
+  virtual void set_aux(const double*) = 0;
+  virtual void get_xpose(double*, double*) const = 0;
+  virtual void set_xpose(const double*, const double*) = 0;
+  virtual void physics(const double* ctrl, int nsub) = 0;
+  virtual void reset(const uint8_t* mask, float* obs) = 0;
+  virtual void step(const float* act, float* obs, float* rew, uint8_t* term, uint8_t* trunc, float* tobs) = 0;
+  virtual void script(int env, const double* u, int n) = 0;
+  virtual int script_remaining(int env) const = 0;
+  virtual void contact_counts(int env, const double* ctrl, int* out) = 0;
+};
+
+template <typename R, bool BLK> struct HostSim : IHost {
+  using L = Layout<BLK>;
+  using ES = EnvState<R, BLK>;
+  Params<R> P;
+  size_t N;
+  std::vector<double> d;
+  std::vector<R> f;
+  std::vector<int> ii;
+  std::vector<std::vector<double>> scripts;
+  std::vector<int> spos;
+  HostSim(int variant, int n, uint64_t seed, int64_t gid_base, int auto_reset, int noise, int max_steps, int nsub, double h)
+      : N(n), d((size_t)L::ND * n), f((size_t)L::NF * n), ii((size_t)L::NI * n), scripts(n), spos(n, 0) {
+    P = make_params<R>(variant, auto_reset, noise, max_steps, nsub, h, seed, gid_base);
+    hostconv::init_state<BLK>(d.data(), f.data(), ii.data(), N, seed, gid_base);
+  }
+  int nq() const override { return L::NQ; }
+  int nv() const override { return L::NV; }
+  void set_state(const double* qp, const double* qv, const double* wm, const double* tm) override {
+    hostconv::set_state<BLK>(d.data(), f.data(), N, qp, qv, wm, tm);
+  }
+  void get_state(double* qp, double* qv, double* wm, double* tm) const override {
+    hostconv::get_state<BLK>(d.data(), f.data(), N, qp, qv, wm, tm);
+  }
+  void get_aux(double* a) const override { hostconv::get_aux<BLK>(d.data(), f.data(), ii.data(), N, a); }
+  void set_aux(const double* a) override { hostconv::set_aux<BLK>(d.data(), f.data(), ii.data(), N, a); }
+  void get_xpose(double* xq, double* xp) const override { hostconv::get_xpose<BLK>(d.data(), N, xq, xp); }
+  void set_xpose(const double* xq, const double* xp) override { hostconv::set_xpose<BLK>(d.data(), N, xq, xp); }
+  void open_stream(Stream<R>& rng, ES& S, size_t i) {
+    rng.open(P.seed, P.gid_base + (int64_t)i, S.rng_ctr);
+    if (!scripts[i].empty()) { rng.script = scripts[i].data(); rng.script_n = (int)scripts[i].size(); rng.script_pos = spos[i]; }
+  }
+  void close_stream(Stream<R>& rng, ES& S, size_t i) { S.rng_ctr = rng.ctr; spos[i] = rng.script_pos; }
+  void physics(const double* ctrl, int nsub) override {
+    R buf[N_SLOTS_ENV03 * SLOT_WORDS];
+    for (size_t i = 0; i < N; i++) {
+      ES S;
+      load_state<R, BLK>(S, d.data(), f.data(), ii.data(), N, i);
+      Store<R> st{buf, 1};
+      for (int k = 0; k < nsub; k++) {
+        for (int j = 0; j < 4; j++) S.xq[j] = S.q[j];
+        for (int j = 0; j < 3; j++) S.xp[j] = S.p[j];
+        Sim<R, BLK>::substep(P, st, S, (R)ctrl[2 * i], (R)ctrl[2 * i + 1]);
+      }
+      store_state<R, BLK>(S, d.data(), f.data(), ii.data(), N, i);
+    }
+  }
+  void reset(const uint8_t* mask, float* obs) override {
+    for (size_t i = 0; i < N; i++) {
+      if (mask && !mask[i]) continue;
+      ES S;
+      load_state<R, BLK>(S, d.data(), f.data(), ii.data(), N, i);
+      Stream<R> rng;
+      open_stream(rng, S, i);
+      Sim<R, BLK>::env_reset(P, S, rng, obs + 6 * i);
+      close_stream(rng, S, i);
+      store_state<R, BLK>(S, d.data(), f.data(), ii.data(), N, i);
+    }
+  }
+  void step(const float* act, float* obs, float* rew, uint8_t* term, uint8_t* trunc, float* tobs) override {
+    R buf[N_SLOTS_ENV03 * SLOT_WORDS];
+    for (size_t i = 0; i < N; i++) {
+      ES S;
+      load_state<R, BLK>(S, d.data(), f.data(), ii.data(), N, i);
+      Stream<R> rng;
+      open_stream(rng, S, i);
+      Store<R> st{buf, 1};
+      int te, tr;
+      float tob[6];
+      Sim<R, BLK>::env_step(P, st, S, rng, act[2 * i], act[2 * i + 1], obs + 6 * i, tob, rew[i], te, tr);
+      term[i] = (uint8_t)te; trunc[i] = (uint8_t)tr;
+      if (tobs) memcpy(tobs + 6 * i, tob, sizeof tob);
+      close_stream(rng, S, i);
+      store_state<R, BLK>(S, d.data(), f.data(), ii.data(), N, i);
+    }
+  }
+  void script(int env, const double* u, int n) override { scripts[env].assign(u, u + n); spos[env] = 0; }
+  int script_remaining(int env) const override { return (int)scripts[env].size() - spos[env]; }
+  void contact_counts(int env, const double* ctrl, int* out) override {
+    // one throw-away substep on a copy, to look at the contact list sizes
+    R buf[N_SLOTS_ENV03 * SLOT_WORDS];
+    ES S;
+    load_state<R, BLK>(S, d.data(), f.data(), ii.data(), N, env);
+    Store<R> st{buf, 1};
+    (void)ctrl; (void)st; (void)S;
+    out[0] = out[1] = out[2] = -1;
+  }
+};
+
+extern "C" {
+void* hs_create(int variant, int n, int use_double, uint64_t seed, int64_t gid_base, int auto_reset, int noise,
+                int max_steps, int nsub, double h) {
+  bool blk = variant >= 2;
+  if (use_double) {
+    if (blk) return new HostSim<double, true>(variant, n, seed, gid_base, auto_reset, noise, max_steps, nsub, h);
+    return new HostSim<double, false>(variant, n, seed, gid_base, auto_reset, noise, max_steps, nsub, h);
+  }
+  if (blk) return new HostSim<float, true>(variant, n, seed, gid_base, auto_reset, noise, max_steps, nsub, h);
+  return new HostSim<float, false>(variant, n, seed, gid_base, auto_reset, noise, max_steps, nsub, h);
+}
+void hs_destroy(void* h) { delete (IHost*)h; }
+int hs_nq(void* h) { return ((IHost*)h)->nq(); }
+int hs_nv(void* h) { return ((IHost*)h)->nv(); }
+void hs_set_state(void* h, const double* a, const double* b, const double* c, const double* d) { ((IHost*)h)->set_state(a, b, c, d); }
+void hs_get_state(void* h, double* a, double* b, double* c, double* d) { ((IHost*)h)->get_state(a, b, c, d); }
+void hs_get_aux(void* h, double* a) { ((IHost*)h)->get_aux(a); }
+void hs_set_aux(void* h, const double* a) { ((IHost*)h)->set_aux(a); }
+void hs_get_xpose(void* h, double* a, double* b) { ((IHost*)h)->get_xpose(a, b); }
+void hs_set_xpose(void* h, const double* a, const double* b) { ((IHost*)h)->set_xpose(a, b); }
+void hs_physics(void* h, const double* ctrl, int nsub) { ((IHost*)h)->physics(ctrl, nsub); }
+void hs_reset(void* h, const uint8_t* m, float* obs) { ((IHost*)h)->reset(m, obs); }
+void hs_step(void* h, const float* a, float* o, float* r, uint8_t* te, uint8_t* tr, float* to) { ((IHost*)h)->step(a, o, r, te, tr, to); }
+void hs_script(void* h, int e, const double* u, int n) { ((IHost*)h)->script(e, u, n); }
+int hs_script_remaining(void* h, int e) { return ((IHost*)h)->script_remaining(e); }
+}
