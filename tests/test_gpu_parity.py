@@ -22,6 +22,8 @@ def _mk(env_id, n, **kw):
                env_index_base=kw.get("env_index_base", 0))
     if "obs_noise" in kw:
         okw["noise"] = kw["obs_noise"]
+    if "max_episode_steps" in kw:
+        okw["max_episode_steps"] = kw["max_episode_steps"]
     orc = O.Oracle(env_id, n, **okw)
     return torch, sim, orc
 
