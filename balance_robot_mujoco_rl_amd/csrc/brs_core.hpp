@@ -24,7 +24,28 @@
 #define BRS_HD inline
 #endif
 
+#ifndef BRS_MASK_HINT
+#define BRS_MASK_HINT 1
+#endif
+#ifndef BRS_FLIP_TOL
+#define BRS_FLIP_TOL 1e-6
+#endif
+#ifndef BRS_UNDAMPED_ITERS
+#define BRS_UNDAMPED_ITERS 3
+#endif
+#ifndef BRS_NEWTON_MODE
+#define BRS_NEWTON_MODE 1
+#endif
+
 namespace brs {
+
+#if defined(BRS_STATS) && !defined(__HIP_DEVICE_COMPILE__)
+struct Stats { long substeps, solves[3], iters[3], passA[3], backtracks[3]; int last_iters[3]; };
+inline Stats& stats() { static thread_local Stats s{}; return s; }
+#define BRS_STAT(expr) do { expr; } while (0)
+#else
+#define BRS_STAT(expr) do { } while (0)
+#endif
 
 // ------------------------------------------------------------------------------------ math wrappers
 BRS_HD float sqrt_(float x) { return sqrtf(x); }
@@ -138,20 +159,35 @@ template <typename R> struct Stream {
 };
 
 // ------------------------------------------------------------------------------------ per-lane contact store
-// 8 words per slot; word w of slot s lives at base[(s*8+w)*stride] (GPU: stride 64 = one LDS row per word)
-enum { SLOT_ROBOT = 0, N_ROBOT_SLOTS = 8, SLOT_BLOCK = 8, N_BLOCK_SLOTS = 4, SLOT_COUPLED = 12, N_COUPLED_SLOTS = 6,
-       N_SLOTS_ENV01 = 8, N_SLOTS_ENV03 = 18, SLOT_WORDS = 8 };
+// floor-contact slots hold 8 words, coupled slots 14; word k of the lane's column lives at base[k*stride]
+// (GPU: stride 64 = one LDS row per word, consecutive lanes on consecutive banks)
+enum { SLOT_ROBOT = 0, N_ROBOT_SLOTS = 8, SLOT_BLOCK = 8, N_BLOCK_SLOTS = 4, N_COUPLED_SLOTS = 4, SLOT_WORDS = 8,
+       COUPLED_WORDS = 14, COUPLED_BASE = (N_ROBOT_SLOTS + N_BLOCK_SLOTS) * SLOT_WORDS,
+       LDS_WORDS_ENV01 = N_ROBOT_SLOTS * SLOT_WORDS, LDS_WORDS_ENV03 = COUPLED_BASE + N_COUPLED_SLOTS * COUPLED_WORDS };
 template <typename R> struct Store {
   R* base;
   int stride;
   BRS_HD R get(int s, int w) const { return base[(s * SLOT_WORDS + w) * stride]; }
   BRS_HD void set(int s, int w, R v) { base[(s * SLOT_WORDS + w) * stride] = v; }
+  BRS_HD R getc(int c, int w) const { return base[(COUPLED_BASE + c * COUPLED_WORDS + w) * stride]; }
+  BRS_HD void setc(int c, int w, R v) { base[(COUPLED_BASE + c * COUPLED_WORDS + w) * stride] = v; }
 };
 // meta word (kept as an exactly-representable small number): sel | maskNew<<2 | maskH<<6
 BRS_HD int meta_sel(int m) { return m & 3; }
 BRS_HD int meta_new(int m) { return (m >> 2) & 15; }
 BRS_HD int meta_h(int m) { return (m >> 6) & 31; }
 BRS_HD int meta_make(int sel, int mnew, int mh) { return sel | (mnew << 2) | (mh << 6); }
+// a slot that held a contact of the same body in the previous substep keeps that contact's final active rows as the
+// first guess of this substep's active set (maskH = 17: guess present, H not built yet; 16: no guess)
+template <typename R> BRS_HD int hint_meta(R oldword, int sel, bool existed) {
+#if BRS_MASK_HINT
+  int old = (int)oldword;
+  bool ok = existed && meta_sel(old) == sel;
+  return meta_make(sel, ok ? meta_new(old) : 0, ok ? 17 : 16);
+#else
+  return meta_make(sel, 0, 16);
+#endif
+}
 
 // ------------------------------------------------------------------------------------ env state (registers)
 template <typename R, bool BLK> struct EnvState {
@@ -172,6 +208,7 @@ template <typename R, bool BLK> struct EnvState {
   int side_front;
   R ep_return;
   int bad;
+  int pnfr, pnfb, pnc;  // contact-list lengths of the previous substep (mask hints; not persisted across launches)
 };
 
 template <typename R> BRS_HD R impedance_(const ContactClass<R>& c, R dist) {
@@ -271,6 +308,7 @@ template <typename R, bool BLK> struct Sim {
     R dTB[3];          // x_T - x_B (world), for coupled contacts
     R a0[NV];          // unconstrained acceleration (body coords)
     int nfr, nfb, nc;  // robot-floor, block-floor, coupled contact counts of this lane
+    int pnfr, pnfb, pnc;  // the same of the previous substep
   };
 
   // wheel hinge column for a contact at r (torso frame) on wheel sel (1 L: axis -x at (-px,0,pz); 2 R: +x at (+px,0,pz))
@@ -299,7 +337,7 @@ template <typename R, bool BLK> struct Sim {
     st.set(s, 4, -c.B * c.mu * vt1);
     st.set(s, 5, -c.B * c.mu * vt2);
     st.set(s, 6, imp * rcp_((1 - imp) * c.cD));
-    st.set(s, 7, (R)meta_make(sel, 0, 16));
+    st.set(s, 7, (R)hint_meta(st.get(s, 7), sel, F.nfr < F.pnfr));
     F.nfr++;
   }
 
@@ -383,7 +421,7 @@ template <typename R, bool BLK> struct Sim {
         st.set(sl, 4, -c.B * c.mu * vt1);
         st.set(sl, 5, -c.B * c.mu * vt2);
         st.set(sl, 6, imp * rcp_((1 - imp) * c.cD));
-        st.set(sl, 7, (R)meta_make(3, 0, 16));
+        st.set(sl, 7, (R)hint_meta(st.get(sl, 7), 3, F.nfb < F.pnfb));
         F.nfb++;
       }
     }
@@ -399,17 +437,54 @@ template <typename R, bool BLK> struct Sim {
     *axis = ax; *sign = pv >= 0 ? (R)1 : (R)-1;
     return best;
   }
-  static BRS_HD void add_coupled(Store<R>& st, Frame& F, const R* rT, const R* nTf, R dist, int sel) {
+  // MuJoCo's mju_makeFrame on a unit normal fw[0..2]: fills tangents fw[3..8]
+  static BRS_HD void make_frame(R* fw) {
+    fw[3] = 0; fw[4] = 0; fw[5] = 0;
+    if (fw[1] < (R)0.5 && fw[1] > (R)-0.5) fw[4] = 1; else fw[5] = 1;
+    R dp = dot_(fw, fw + 3);
+    fw[3] -= dp * fw[0]; fw[4] -= dp * fw[1]; fw[5] -= dp * fw[2];
+    R il = rsqrt_(dot_(fw + 3, fw + 3));
+    fw[3] *= il; fw[4] *= il; fw[5] *= il;
+    cross_(fw, fw + 3, fw + 6);
+  }
+  // coupled record (14 words): rT(3) torso frame, rB(3) block frame, nW(3) world normal robot->block, An, Bt1, Bt2, D, meta
+  static BRS_HD void add_coupled(const Params<R>& P, Store<R>& st, Frame& F, const ES& S, const R* rT, const R* nTf, R dist,
+                                 int sel) {
     if (F.nc >= N_COUPLED_SLOTS) return;
-    int s = SLOT_COUPLED + F.nc;
-    st.set(s, 0, rT[0]); st.set(s, 1, rT[1]); st.set(s, 2, rT[2]);
-    st.set(s, 3, nTf[0]); st.set(s, 4, nTf[1]); st.set(s, 5, nTf[2]);
-    st.set(s, 6, dist);
-    st.set(s, 7, (R)meta_make(sel, 0, 16));
+    const ContactClass<R>& c = P.cc[CC_BLOCK_ROBOT];
+    R fw[9], pw[3], rB[3], wc[3], t[3];
+    mul_(F.RT, nTf, fw);
+    R il = rsqrt_(dot_(fw, fw));
+    fw[0] *= il; fw[1] *= il; fw[2] *= il;
+    make_frame(fw);
+    mul_(F.RT, rT, pw);
+    pw[0] += F.dTB[0]; pw[1] += F.dTB[1]; pw[2] += F.dTB[2];
+    mulT_(F.RB, pw, rB);
+    wheel_col(P, sel, rT, wc);
+    // relative point velocity (block minus robot), world frame
+    cross_(S.w, rT, t);
+    R wsel = sel == 1 ? S.ww[0] : (sel == 2 ? S.ww[1] : (R)0);
+    R pT[3] = {t[0] + wsel * wc[0], t[1] + wsel * wc[1], t[2] + wsel * wc[2]}, pTw[3], pBw[3];
+    mul_(F.RT, pT, pTw);
+    cross_(S.bw, rB, t);
+    mul_(F.RB, t, pBw);
+    R rel[3] = {S.bv[0] + pBw[0] - S.v[0] - pTw[0], S.bv[1] + pBw[1] - S.v[1] - pTw[1], S.bv[2] + pBw[2] - S.v[2] - pTw[2]};
+    R vn = dot_(fw, rel), vt1 = dot_(fw + 3, rel), vt2 = dot_(fw + 6, rel);
+    R imp = impedance_(c, dist);
+    R cD = sel == 0 ? c.cD : P.cD_block_wheel;
+    int k = F.nc;
+    st.setc(k, 0, rT[0]); st.setc(k, 1, rT[1]); st.setc(k, 2, rT[2]);
+    st.setc(k, 3, rB[0]); st.setc(k, 4, rB[1]); st.setc(k, 5, rB[2]);
+    st.setc(k, 6, fw[0]); st.setc(k, 7, fw[1]); st.setc(k, 8, fw[2]);
+    st.setc(k, 9, -c.B * vn - c.K * imp * (dist - c.margin));
+    st.setc(k, 10, -c.B * c.mu * vt1);
+    st.setc(k, 11, -c.B * c.mu * vt2);
+    st.setc(k, 12, imp * rcp_((1 - imp) * cD));
+    st.setc(k, 13, (R)hint_meta(st.getc(k, 13), sel, k < F.pnc));
     F.nc++;
   }
   // everything in the TORSO frame: block centre cB, block axes as columns of RTB = RT^T RB
-  static BRS_HD void collide_coupled(const Params<R>& P, Store<R>& st, Frame& F) {
+  static BRS_HD void collide_coupled(const Params<R>& P, Store<R>& st, Frame& F, const ES& S) {
     const ContactClass<R>& c = P.cc[CC_BLOCK_ROBOT];
     R dW[3] = {-F.dTB[0], -F.dTB[1], -F.dTB[2]};  // x_B - x_T (world)
     R cB[3];
@@ -476,7 +551,7 @@ template <typename R, bool BLK> struct Sim {
             for (int i = 0; i < 3; i++) lat = lat && (i == k || abs_(p[i]) <= sT[i] + c.margin);
             if (dist < c.margin && lat) {
               R pos[3] = {p[0] - nrm[0] * dist * (R)0.5, p[1] - nrm[1] * dist * (R)0.5, p[2] + P.torso_cz - nrm[2] * dist * (R)0.5};
-              add_coupled(st, F, pos, nrm, dist, 0);
+              add_coupled(P, st, F, S, pos, nrm, dist, 0);
               cnt++;
             }
             if (dist < fb_dist) {
@@ -488,7 +563,7 @@ template <typename R, bool BLK> struct Sim {
           if (cnt == 0 && fb_dist < c.margin) {
             R pos[3] = {fb_pos[0] - nrm[0] * fb_dist * (R)0.5, fb_pos[1] - nrm[1] * fb_dist * (R)0.5,
                         fb_pos[2] + P.torso_cz - nrm[2] * fb_dist * (R)0.5};
-            add_coupled(st, F, pos, nrm, fb_dist, 0);
+            add_coupled(P, st, F, S, pos, nrm, fb_dist, 0);
           }
         } else {
           const int j = bestax - 3;
@@ -515,7 +590,7 @@ template <typename R, bool BLK> struct Sim {
             for (int i = 0; i < 3; i++) lat = lat && (i == j || abs_(pB[i]) <= s + c.margin);
             if (dist < c.margin && lat) {
               R pos[3] = {loc[0] + nrm[0] * dist * (R)0.5, loc[1] + nrm[1] * dist * (R)0.5, loc[2] + P.torso_cz + nrm[2] * dist * (R)0.5};
-              add_coupled(st, F, pos, nrm, dist, 0);
+              add_coupled(P, st, F, S, pos, nrm, dist, 0);
               cnt++;
             }
             if (dist < fb_dist) {
@@ -531,7 +606,7 @@ template <typename R, bool BLK> struct Sim {
           if (cnt == 0 && fb_dist < c.margin) {
             R pos[3] = {fb_pos[0] + nrm[0] * fb_dist * (R)0.5, fb_pos[1] + nrm[1] * fb_dist * (R)0.5,
                         fb_pos[2] + P.torso_cz + nrm[2] * fb_dist * (R)0.5};
-            add_coupled(st, F, pos, nrm, fb_dist, 0);
+            add_coupled(P, st, F, S, pos, nrm, fb_dist, 0);
           }
         }
       }
@@ -583,300 +658,288 @@ template <typename R, bool BLK> struct Sim {
           }
         }
       }
-      if (found) add_coupled(st, F, bpos, bn, best, wsel);
+      if (found) add_coupled(P, st, F, S, bpos, bn, best, wsel);
     }
   }
 
-  // derived data of one coupled contact (recomputed per pass; coupled contacts are rare)
+  // per-pass data of one coupled contact: frame axes (n,t1,t2) rotated into both body frames
   struct Coupled {
-    R rT[3], rB[3], dT[3][3], dB[3][3], wc[3];  // frame axes (n,t1,t2) in torso / block coords
+    R rT[3], rB[3], dT[3][3], dB[3][3], wc[3];
     R An, Bt1, Bt2, D, mu;
-    int sel;
+    int sel, meta;
   };
-  static BRS_HD void coupled_derive(const Params<R>& P, const Store<R>& st, const Frame& F, const ES& S, int s, Coupled& C) {
-    const ContactClass<R>& c = P.cc[CC_BLOCK_ROBOT];
-    int meta = (int)st.get(s, 7);
-    C.sel = meta_sel(meta);
-    R nTf[3];
-#pragma unroll
-    for (int j = 0; j < 3; j++) { C.rT[j] = st.get(s, j); nTf[j] = st.get(s, 3 + j); }
-    R dist = st.get(s, 6);
-    // world frame of the contact: MuJoCo's mju_makeFrame on the world normal
+  static BRS_HD void coupled_load(const Params<R>& P, const Store<R>& st, const Frame& F, int c, Coupled& C) {
     R fw[9];
-    mul_(F.RT, nTf, fw);
-    R il = rsqrt_(dot_(fw, fw));
-    fw[0] *= il; fw[1] *= il; fw[2] *= il;
-    fw[3] = 0; fw[4] = 0; fw[5] = 0;
-    if (fw[1] < (R)0.5 && fw[1] > (R)-0.5) fw[4] = 1; else fw[5] = 1;
-    R dp = dot_(fw, fw + 3);
-    fw[3] -= dp * fw[0]; fw[4] -= dp * fw[1]; fw[5] -= dp * fw[2];
-    il = rsqrt_(dot_(fw + 3, fw + 3));
-    fw[3] *= il; fw[4] *= il; fw[5] *= il;
-    cross_(fw, fw + 3, fw + 6);
-    // contact point relative to the block, block frame
-    R pw[3];
-    mul_(F.RT, C.rT, pw);
-    pw[0] += F.dTB[0]; pw[1] += F.dTB[1]; pw[2] += F.dTB[2];
-    mulT_(F.RB, pw, C.rB);
+#pragma unroll
+    for (int j = 0; j < 3; j++) { C.rT[j] = st.getc(c, j); C.rB[j] = st.getc(c, 3 + j); fw[j] = st.getc(c, 6 + j); }
+    C.An = st.getc(c, 9); C.Bt1 = st.getc(c, 10); C.Bt2 = st.getc(c, 11); C.D = st.getc(c, 12);
+    C.meta = (int)st.getc(c, 13);
+    C.sel = meta_sel(C.meta);
+    C.mu = P.cc[CC_BLOCK_ROBOT].mu;
+    make_frame(fw);
 #pragma unroll
     for (int k = 0; k < 3; k++) { mulT_(F.RT, fw + 3 * k, C.dT[k]); mulT_(F.RB, fw + 3 * k, C.dB[k]); }
     wheel_col(P, C.sel, C.rT, C.wc);
-    // relative point velocity (block minus robot) in the contact frame
-    R uT[3], uB[3], t[3];
-    mulT_(F.RT, S.v, uT);
-    mulT_(F.RB, S.bv, uB);
-    cross_(S.w, C.rT, t);
-    R wsel = C.sel == 1 ? S.ww[0] : (C.sel == 2 ? S.ww[1] : (R)0);
-    R pvT[3] = {uT[0] + t[0] + wsel * C.wc[0], uT[1] + t[1] + wsel * C.wc[1], uT[2] + t[2] + wsel * C.wc[2]};
-    cross_(S.bw, C.rB, t);
-    R pvB[3] = {uB[0] + t[0], uB[1] + t[1], uB[2] + t[2]};
-    R vn = dot_(C.dB[0], pvB) - dot_(C.dT[0], pvT), vt1 = dot_(C.dB[1], pvB) - dot_(C.dT[1], pvT),
-      vt2 = dot_(C.dB[2], pvB) - dot_(C.dT[2], pvT);
-    R imp = impedance_(c, dist);
-    C.mu = c.mu;
-    C.An = -c.B * vn - c.K * imp * (dist - c.margin);
-    C.Bt1 = -c.B * c.mu * vt1;
-    C.Bt2 = -c.B * c.mu * vt2;
-    R cD = C.sel == 0 ? c.cD : P.cD_block_wheel;
-    C.D = imp * rcp_((1 - imp) * cD);
   }
 
-  // ---- pass A: cost, gradient, constraint force and active masks at x
-  static BRS_HD void passA(const Params<R>& P, Store<R>& st, const Frame& F, const ES& S, const R* x, R& cost, R* grad,
-                           R* fcon, bool& same) {
-    R dx[NV], Md[NV];
+  // ---- Newton solver of the convex acceleration problem  min 1/2 (x-a0)^T M (x-a0) + sum 1/2 D min(0, J x - aref)^2
+  // over all NV dofs.  Every lane walks its own contact lists (robot<->floor, block<->floor, block<->robot), so a
+  // wave pays max-over-lanes of the list lengths, not a sum over "modes".  One iteration = assemble (H and rhs of
+  // the quadratic piece selected by the active rows; on the first iteration the rows are evaluated at the warm
+  // start inside the same pass) -> Cholesky solve -> passA at the new point (cost, J^T f, active rows).  Exact
+  // termination: a full step that reproduces its own active set is the minimiser of the piecewise-quadratic cost.
+  struct Solver {
+    static constexpr int NN = NV, NHH = NH;
+
+    static BRS_HD void gauss(const Params<R>& P, const R* x, const R* a0, R* Md, R& cst) {
+      R dx[NN];
 #pragma unroll
-    for (int i = 0; i < NV; i++) { dx[i] = x[i] - F.a0[i]; fcon[i] = 0; }
-    mmul_(P, dx, Md);
-    if constexpr (BLK) {
+      for (int i = 0; i < NN; i++) dx[i] = x[i] - a0[i];
+      mmul_(P, dx, Md);
+      if constexpr (BLK) {
 #pragma unroll
-      for (int i = 0; i < 3; i++) { Md[8 + i] = P.mB * dx[8 + i]; Md[11 + i] = P.IB * dx[11 + i]; }
+        for (int i = 0; i < 3; i++) { Md[8 + i] = P.mB * dx[8 + i]; Md[11 + i] = P.IB * dx[11 + i]; }
+      }
+      cst = 0;
+#pragma unroll
+      for (int i = 0; i < NN; i++) cst += (R)0.5 * dx[i] * Md[i];
     }
-    R cst = 0;
-#pragma unroll
-    for (int i = 0; i < NV; i++) cst += (R)0.5 * dx[i] * Md[i];
-    bool sm = true;
-    // robot <-> floor
-    for (int c = 0; c < F.nfr; c++) {
-      int s = SLOT_ROBOT + c;
-      R r[3] = {st.get(s, 0), st.get(s, 1), st.get(s, 2)};
-      R An = st.get(s, 3), Bt1 = st.get(s, 4), Bt2 = st.get(s, 5), D = st.get(s, 6);
-      int meta = (int)st.get(s, 7), sel = meta_sel(meta);
-      R mu = sel == 0 ? P.cc[CC_TORSO_FLOOR].mu : P.cc[CC_WHEEL_FLOOR].mu;
-      R wc[3], t[3];
-      wheel_col(P, sel, r, wc);
-      cross_(x + 3, r, t);
-      R xs = sel == 1 ? x[6] : (sel == 2 ? x[7] : (R)0);
-      R pa[3] = {x[0] + t[0] + xs * wc[0], x[1] + t[1] + xs * wc[1], x[2] + t[2] + xs * wc[2]};
-      R cn = dot_(F.nT, pa) - An, c1 = mu * dot_(F.t1T, pa) - Bt1, c2 = mu * dot_(F.t2T, pa) - Bt2;
+
+    // rows of one contact from (cn, c1, c2): e = cn +- c1, cn +- c2; returns mask, accumulates cost; l = max(-e, 0)
+    static BRS_HD int rows_(R cn, R c1, R c2, R D, R& cst, R* l, int mh, bool& sm) {
       R e1 = cn + c1, e2 = cn - c1, e3 = cn + c2, e4 = cn - c2;
+      l[0] = max_(-e1, (R)0); l[1] = max_(-e2, (R)0); l[2] = max_(-e3, (R)0); l[3] = max_(-e4, (R)0);
+      cst += (R)0.5 * D * (l[0] * l[0] + l[1] * l[1] + l[2] * l[2] + l[3] * l[3]);
       int mk = (e1 < 0 ? 1 : 0) | (e2 < 0 ? 2 : 0) | (e3 < 0 ? 4 : 0) | (e4 < 0 ? 8 : 0);
-      R l1 = max_(-e1, (R)0), l2 = max_(-e2, (R)0), l3 = max_(-e3, (R)0), l4 = max_(-e4, (R)0);
-      cst += (R)0.5 * D * (l1 * l1 + l2 * l2 + l3 * l3 + l4 * l4);
-      R fn = D * (l1 + l2 + l3 + l4), f1 = D * mu * (l1 - l2), f2 = D * mu * (l3 - l4);
-      R fb[3] = {F.nT[0] * fn + F.t1T[0] * f1 + F.t2T[0] * f2, F.nT[1] * fn + F.t1T[1] * f1 + F.t2T[1] * f2,
-                 F.nT[2] * fn + F.t1T[2] * f1 + F.t2T[2] * f2};
-      cross_(r, fb, t);
-      fcon[0] += fb[0]; fcon[1] += fb[1]; fcon[2] += fb[2];
-      fcon[3] += t[0]; fcon[4] += t[1]; fcon[5] += t[2];
-      R fw = dot_(wc, fb);
-      fcon[6] += sel == 1 ? fw : (R)0;
-      fcon[7] += sel == 2 ? fw : (R)0;
-      if (mk != meta_h(meta)) sm = false;
-      st.set(s, 7, (R)meta_make(sel, mk, meta_h(meta)));
+      // a row that sits on its own boundary (|e| below the rounding of its terms) carries no force either way:
+      // its flip does not invalidate the quadratic piece H was built for
+      R tol = (R)BRS_FLIP_TOL * (abs_(cn) + abs_(c1) + abs_(c2));
+      int df = mk ^ mh;
+      if (((df & 1) && abs_(e1) > tol) || ((df & 2) && abs_(e2) > tol) || ((df & 4) && abs_(e3) > tol) || ((df & 8) && abs_(e4) > tol) || mh > 15)
+        sm = false;
+      return mk;
     }
-    if constexpr (BLK) {
-      for (int c = 0; c < F.nfb; c++) {
-        int s = SLOT_BLOCK + c;
+
+    // pass A: cost, constraint force J^T f and active-row masks at x; same = every mask equals the one H was built with
+    static BRS_HD void passA(const Params<R>& P, Store<R>& st, const Frame& F, const R* x, const R* a0, R& cost, R* fcon,
+                             bool& same) {
+      R Md[NN], cst, l[4];
+      gauss(P, x, a0, Md, cst);
+#pragma unroll
+      for (int i = 0; i < NN; i++) fcon[i] = 0;
+      bool sm = true;
+      for (int c = 0; c < F.nfr; c++) {
+        int s = SLOT_ROBOT + c;
         R r[3] = {st.get(s, 0), st.get(s, 1), st.get(s, 2)};
         R An = st.get(s, 3), Bt1 = st.get(s, 4), Bt2 = st.get(s, 5), D = st.get(s, 6);
-        int meta = (int)st.get(s, 7);
-        R mu = P.cc[CC_BLOCK_FLOOR].mu;
-        R t[3];
-        cross_(x + 11, r, t);
-        R pa[3] = {x[8] + t[0], x[9] + t[1], x[10] + t[2]};
-        R cn = dot_(F.nB, pa) - An, c1 = mu * dot_(F.t1B, pa) - Bt1, c2 = mu * dot_(F.t2B, pa) - Bt2;
-        R e1 = cn + c1, e2 = cn - c1, e3 = cn + c2, e4 = cn - c2;
-        int mk = (e1 < 0 ? 1 : 0) | (e2 < 0 ? 2 : 0) | (e3 < 0 ? 4 : 0) | (e4 < 0 ? 8 : 0);
-        R l1 = max_(-e1, (R)0), l2 = max_(-e2, (R)0), l3 = max_(-e3, (R)0), l4 = max_(-e4, (R)0);
-        cst += (R)0.5 * D * (l1 * l1 + l2 * l2 + l3 * l3 + l4 * l4);
-        R fn = D * (l1 + l2 + l3 + l4), f1 = D * mu * (l1 - l2), f2 = D * mu * (l3 - l4);
-        R fb[3] = {F.nB[0] * fn + F.t1B[0] * f1 + F.t2B[0] * f2, F.nB[1] * fn + F.t1B[1] * f1 + F.t2B[1] * f2,
-                   F.nB[2] * fn + F.t1B[2] * f1 + F.t2B[2] * f2};
+        int meta = (int)st.get(s, 7), sel = meta_sel(meta);
+        R mu = sel == 0 ? P.cc[CC_TORSO_FLOOR].mu : P.cc[CC_WHEEL_FLOOR].mu;
+        R wc[3], t[3];
+        wheel_col(P, sel, r, wc);
+        cross_(x + 3, r, t);
+        R xs = sel == 1 ? x[6] : (sel == 2 ? x[7] : (R)0);
+        R pa[3] = {x[0] + t[0] + xs * wc[0], x[1] + t[1] + xs * wc[1], x[2] + t[2] + xs * wc[2]};
+        int mk = rows_(dot_(F.nT, pa) - An, mu * dot_(F.t1T, pa) - Bt1, mu * dot_(F.t2T, pa) - Bt2, D, cst, l, meta_h(meta), sm);
+        R fn = D * (l[0] + l[1] + l[2] + l[3]), f1 = D * mu * (l[0] - l[1]), f2 = D * mu * (l[2] - l[3]);
+        R fb[3] = {F.nT[0] * fn + F.t1T[0] * f1 + F.t2T[0] * f2, F.nT[1] * fn + F.t1T[1] * f1 + F.t2T[1] * f2,
+                   F.nT[2] * fn + F.t1T[2] * f1 + F.t2T[2] * f2};
         cross_(r, fb, t);
-        fcon[8] += fb[0]; fcon[9] += fb[1]; fcon[10] += fb[2];
-        fcon[11] += t[0]; fcon[12] += t[1]; fcon[13] += t[2];
-        if (mk != meta_h(meta)) sm = false;
-        st.set(s, 7, (R)meta_make(3, mk, meta_h(meta)));
-      }
-      for (int c = 0; c < F.nc; c++) {
-        int s = SLOT_COUPLED + c;
-        Coupled C;
-        coupled_derive(P, st, F, S, s, C);
-        int meta = (int)st.get(s, 7);
-        R t[3];
-        cross_(x + 3, C.rT, t);
-        R xs = C.sel == 1 ? x[6] : (C.sel == 2 ? x[7] : (R)0);
-        R paT[3] = {x[0] + t[0] + xs * C.wc[0], x[1] + t[1] + xs * C.wc[1], x[2] + t[2] + xs * C.wc[2]};
-        cross_(x + 11, C.rB, t);
-        R paB[3] = {x[8] + t[0], x[9] + t[1], x[10] + t[2]};
-        R cn = dot_(C.dB[0], paB) - dot_(C.dT[0], paT) - C.An;
-        R c1 = C.mu * (dot_(C.dB[1], paB) - dot_(C.dT[1], paT)) - C.Bt1;
-        R c2 = C.mu * (dot_(C.dB[2], paB) - dot_(C.dT[2], paT)) - C.Bt2;
-        R e1 = cn + c1, e2 = cn - c1, e3 = cn + c2, e4 = cn - c2;
-        int mk = (e1 < 0 ? 1 : 0) | (e2 < 0 ? 2 : 0) | (e3 < 0 ? 4 : 0) | (e4 < 0 ? 8 : 0);
-        R l1 = max_(-e1, (R)0), l2 = max_(-e2, (R)0), l3 = max_(-e3, (R)0), l4 = max_(-e4, (R)0);
-        cst += (R)0.5 * C.D * (l1 * l1 + l2 * l2 + l3 * l3 + l4 * l4);
-        R fn = C.D * (l1 + l2 + l3 + l4), f1 = C.D * C.mu * (l1 - l2), f2 = C.D * C.mu * (l3 - l4);
-        R fT[3], fB[3];
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-          fT[j] = -(C.dT[0][j] * fn + C.dT[1][j] * f1 + C.dT[2][j] * f2);
-          fB[j] = C.dB[0][j] * fn + C.dB[1][j] * f1 + C.dB[2][j] * f2;
-        }
-        cross_(C.rT, fT, t);
-        fcon[0] += fT[0]; fcon[1] += fT[1]; fcon[2] += fT[2];
+        fcon[0] += fb[0]; fcon[1] += fb[1]; fcon[2] += fb[2];
         fcon[3] += t[0]; fcon[4] += t[1]; fcon[5] += t[2];
-        R fw = dot_(C.wc, fT);
-        fcon[6] += C.sel == 1 ? fw : (R)0;
-        fcon[7] += C.sel == 2 ? fw : (R)0;
-        cross_(C.rB, fB, t);
-        fcon[8] += fB[0]; fcon[9] += fB[1]; fcon[10] += fB[2];
-        fcon[11] += t[0]; fcon[12] += t[1]; fcon[13] += t[2];
-        if (mk != meta_h(meta)) sm = false;
-        st.set(s, 7, (R)meta_make(C.sel, mk, meta_h(meta)));
+        R fw = dot_(wc, fb);
+        fcon[6] += sel == 1 ? fw : (R)0;
+        fcon[7] += sel == 2 ? fw : (R)0;
+        st.set(s, 7, (R)meta_make(sel, mk, meta_h(meta)));
       }
-    }
+      if constexpr (BLK) {
+        for (int c = 0; c < F.nfb; c++) {
+          int s = SLOT_BLOCK + c;
+          R r[3] = {st.get(s, 0), st.get(s, 1), st.get(s, 2)};
+          R An = st.get(s, 3), Bt1 = st.get(s, 4), Bt2 = st.get(s, 5), D = st.get(s, 6);
+          int meta = (int)st.get(s, 7);
+          R mu = P.cc[CC_BLOCK_FLOOR].mu;
+          R t[3];
+          cross_(x + 11, r, t);
+          R pa[3] = {x[8] + t[0], x[9] + t[1], x[10] + t[2]};
+          int mk = rows_(dot_(F.nB, pa) - An, mu * dot_(F.t1B, pa) - Bt1, mu * dot_(F.t2B, pa) - Bt2, D, cst, l, meta_h(meta), sm);
+          R fn = D * (l[0] + l[1] + l[2] + l[3]), f1 = D * mu * (l[0] - l[1]), f2 = D * mu * (l[2] - l[3]);
+          R fb[3] = {F.nB[0] * fn + F.t1B[0] * f1 + F.t2B[0] * f2, F.nB[1] * fn + F.t1B[1] * f1 + F.t2B[1] * f2,
+                     F.nB[2] * fn + F.t1B[2] * f1 + F.t2B[2] * f2};
+          cross_(r, fb, t);
+          fcon[8] += fb[0]; fcon[9] += fb[1]; fcon[10] += fb[2];
+          fcon[11] += t[0]; fcon[12] += t[1]; fcon[13] += t[2];
+            st.set(s, 7, (R)meta_make(3, mk, meta_h(meta)));
+        }
+        for (int c = 0; c < F.nc; c++) {
+          Coupled C;
+          coupled_load(P, st, F, c, C);
+          R t[3];
+          cross_(x + 3, C.rT, t);
+          R xs = C.sel == 1 ? x[6] : (C.sel == 2 ? x[7] : (R)0);
+          R paT[3] = {x[0] + t[0] + xs * C.wc[0], x[1] + t[1] + xs * C.wc[1], x[2] + t[2] + xs * C.wc[2]};
+          cross_(x + 11, C.rB, t);
+          R paB[3] = {x[8] + t[0], x[9] + t[1], x[10] + t[2]};
+          int mk = rows_(dot_(C.dB[0], paB) - dot_(C.dT[0], paT) - C.An, C.mu * (dot_(C.dB[1], paB) - dot_(C.dT[1], paT)) - C.Bt1,
+                         C.mu * (dot_(C.dB[2], paB) - dot_(C.dT[2], paT)) - C.Bt2, C.D, cst, l, meta_h(C.meta), sm);
+          R fn = C.D * (l[0] + l[1] + l[2] + l[3]), f1 = C.D * C.mu * (l[0] - l[1]), f2 = C.D * C.mu * (l[2] - l[3]);
+          R fT[3], fB[3];
 #pragma unroll
-    for (int i = 0; i < NV; i++) grad[i] = Md[i] - fcon[i];
-    cost = cst;
-    same = sm;
-  }
+          for (int j = 0; j < 3; j++) {
+            fT[j] = -(C.dT[0][j] * fn + C.dT[1][j] * f1 + C.dT[2][j] * f2);
+            fB[j] = C.dB[0][j] * fn + C.dB[1][j] * f1 + C.dB[2][j] * f2;
+          }
+          cross_(C.rT, fT, t);
+          fcon[0] += fT[0]; fcon[1] += fT[1]; fcon[2] += fT[2];
+          fcon[3] += t[0]; fcon[4] += t[1]; fcon[5] += t[2];
+          R fw = dot_(C.wc, fT);
+          fcon[6] += C.sel == 1 ? fw : (R)0;
+          fcon[7] += C.sel == 2 ? fw : (R)0;
+          cross_(C.rB, fB, t);
+          fcon[8] += fB[0]; fcon[9] += fB[1]; fcon[10] += fB[2];
+          fcon[11] += t[0]; fcon[12] += t[1]; fcon[13] += t[2];
+          st.setc(c, 13, (R)meta_make(C.sel, mk, meta_h(C.meta)));
+        }
+      }
+      cost = cst;
+      same = sm;
+    }
 
-  // ---- pass B: H = M + sum over active rows D j j^T  (packed lower triangle), then Newton direction
-  static BRS_HD void add_row(R* H, const R* j, R D) {
-#pragma unroll
-    for (int a = 0; a < NV; a++) {
-      R da = D * j[a];
-#pragma unroll
-      for (int b = 0; b <= a; b++) H[tri(a, b)] += da * j[b];
-    }
-  }
-  static BRS_HD void add_row_robot(R* H, const R* j, R D) {
-#pragma unroll
-    for (int a = 0; a < 8; a++) {
-      R da = D * j[a];
-#pragma unroll
-      for (int b = 0; b <= a; b++) H[tri(a, b)] += da * j[b];
-    }
-  }
-  static BRS_HD void add_row_block(R* H, const R* j, R D) {  // j[0..5] -> dofs 8..13
-#pragma unroll
-    for (int a = 0; a < 6; a++) {
-      R da = D * j[a];
-#pragma unroll
-      for (int b = 0; b <= a; b++) H[tri(8 + a, 8 + b)] += da * j[b];
-    }
-  }
-
-  static BRS_HD void newton_dir(const Params<R>& P, Store<R>& st, const Frame& F, const ES& S, const R* grad, R* dir) {
-    R H[NH];
-#pragma unroll
-    for (int i = 0; i < NH; i++) H[i] = 0;
-    H[tri(0, 0)] = P.m; H[tri(1, 1)] = P.m; H[tri(2, 2)] = P.m;
-    H[tri(3, 3)] = P.Ixx; H[tri(4, 4)] = P.Iyy; H[tri(5, 5)] = P.Izz; H[tri(6, 6)] = P.Ia; H[tri(7, 7)] = P.Ia;
-    H[tri(4, 0)] = P.mcz; H[tri(3, 1)] = -P.mcz; H[tri(6, 3)] = -P.Ia; H[tri(7, 3)] = P.Ia;
-    if constexpr (BLK) {
-#pragma unroll
-      for (int i = 0; i < 3; i++) { H[tri(8 + i, 8 + i)] = P.mB; H[tri(11 + i, 11 + i)] = P.IB; }
-    }
-    for (int c = 0; c < F.nfr; c++) {
-      int s = SLOT_ROBOT + c;
-      R r[3] = {st.get(s, 0), st.get(s, 1), st.get(s, 2)};
-      R D = st.get(s, 6);
-      int meta = (int)st.get(s, 7), sel = meta_sel(meta), mk = meta_new(meta);
-      st.set(s, 7, (R)meta_make(sel, mk, mk));
-      R mu = sel == 0 ? P.cc[CC_TORSO_FLOOR].mu : P.cc[CC_WHEEL_FLOOR].mu;
-      R wc[3], rn[3], r1[3], r2[3];
-      wheel_col(P, sel, r, wc);
-      cross_(r, F.nT, rn); cross_(r, F.t1T, r1); cross_(r, F.t2T, r2);
-      R wn = dot_(wc, F.nT), w1 = dot_(wc, F.t1T), w2 = dot_(wc, F.t2T);
-      R gn[8] = {F.nT[0], F.nT[1], F.nT[2], rn[0], rn[1], rn[2], sel == 1 ? wn : (R)0, sel == 2 ? wn : (R)0};
-      R g1[8] = {F.t1T[0], F.t1T[1], F.t1T[2], r1[0], r1[1], r1[2], sel == 1 ? w1 : (R)0, sel == 2 ? w1 : (R)0};
-      R g2[8] = {F.t2T[0], F.t2T[1], F.t2T[2], r2[0], r2[1], r2[2], sel == 1 ? w2 : (R)0, sel == 2 ? w2 : (R)0};
-      R j[8];
+    // the 4 pyramid rows of one contact into H (dofs A0..A0+NA) and rhs; on `first` the rows are evaluated at x
+    template <int A0, int NA>
+    static BRS_HD int rows_into(R* H, R* rhs, const R* gn, const R* g1, const R* g2, R mu, R D, R An, R Bt1, R Bt2,
+                                bool eval, int mnew, const R* x, R& cst) {
+      int mk = 0;
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         R sg = (k & 1) ? -mu : mu;
+        R j[NA];
 #pragma unroll
-        for (int i = 0; i < 8; i++) j[i] = gn[i] + sg * (k < 2 ? g1[i] : g2[i]);
-        add_row_robot(H, j, (mk >> k) & 1 ? D : (R)0);
+        for (int i = 0; i < NA; i++) j[i] = gn[i] + sg * (k < 2 ? g1[i] : g2[i]);
+        R aref = An + ((k & 1) ? (R)-1 : (R)1) * (k < 2 ? Bt1 : Bt2);
+        bool act;
+        if (eval) {
+          R e = -aref;
+#pragma unroll
+          for (int i = 0; i < NA; i++) e += j[i] * x[A0 + i];
+          act = e < 0;
+        } else
+          act = (mnew >> k) & 1;
+        mk |= act ? (1 << k) : 0;
+        R Dk = act ? D : (R)0, da = Dk * aref;
+#pragma unroll
+        for (int a = 0; a < NA; a++) {
+          R dj = Dk * j[a];
+          rhs[A0 + a] += da * j[a];
+#pragma unroll
+          for (int b = 0; b <= a; b++) H[tri(A0 + a, A0 + b)] += dj * j[b];
+        }
       }
+      return mk;
     }
-    bool coupled = false;
-    if constexpr (BLK) {
-      for (int c = 0; c < F.nfb; c++) {
-        int s = SLOT_BLOCK + c;
+
+    // assemble H = M + sum_active D j j^T and rhs = M a0 + sum_active D aref j; cost_x = cost at x (only on `first`)
+    static BRS_HD void assemble(const Params<R>& P, Store<R>& st, const Frame& F, const R* x, const R* a0, bool first, R* H,
+                                R* rhs, R& cost_x) {
+#pragma unroll
+      for (int i = 0; i < NHH; i++) H[i] = 0;
+      H[tri(0, 0)] = P.m; H[tri(1, 1)] = P.m; H[tri(2, 2)] = P.m;
+      H[tri(3, 3)] = P.Ixx; H[tri(4, 4)] = P.Iyy; H[tri(5, 5)] = P.Izz; H[tri(6, 6)] = P.Ia; H[tri(7, 7)] = P.Ia;
+      H[tri(4, 0)] = P.mcz; H[tri(3, 1)] = -P.mcz; H[tri(6, 3)] = -P.Ia; H[tri(7, 3)] = P.Ia;
+      mmul_(P, a0, rhs);
+      if constexpr (BLK) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          H[tri(8 + i, 8 + i)] = P.mB; H[tri(11 + i, 11 + i)] = P.IB;
+          rhs[8 + i] = P.mB * a0[8 + i]; rhs[11 + i] = P.IB * a0[11 + i];
+        }
+      }
+      R cst = 0;
+      if (first) { R Md[NN]; gauss(P, x, a0, Md, cst); }
+      for (int c = 0; c < F.nfr; c++) {
+        int s = SLOT_ROBOT + c;
         R r[3] = {st.get(s, 0), st.get(s, 1), st.get(s, 2)};
-        R D = st.get(s, 6);
-        int meta = (int)st.get(s, 7), mk = meta_new(meta);
-        st.set(s, 7, (R)meta_make(3, mk, mk));
-        R mu = P.cc[CC_BLOCK_FLOOR].mu;
-        R rn[3], r1[3], r2[3];
-        cross_(r, F.nB, rn); cross_(r, F.t1B, r1); cross_(r, F.t2B, r2);
-        R gn[6] = {F.nB[0], F.nB[1], F.nB[2], rn[0], rn[1], rn[2]};
-        R g1[6] = {F.t1B[0], F.t1B[1], F.t1B[2], r1[0], r1[1], r1[2]};
-        R g2[6] = {F.t2B[0], F.t2B[1], F.t2B[2], r2[0], r2[1], r2[2]};
-        R j[6];
+        R An = st.get(s, 3), Bt1 = st.get(s, 4), Bt2 = st.get(s, 5), D = st.get(s, 6);
+        int meta = (int)st.get(s, 7), sel = meta_sel(meta);
+        R mu = sel == 0 ? P.cc[CC_TORSO_FLOOR].mu : P.cc[CC_WHEEL_FLOOR].mu;
+        R wc[3], rn[3], r1[3], r2[3];
+        wheel_col(P, sel, r, wc);
+        cross_(r, F.nT, rn); cross_(r, F.t1T, r1); cross_(r, F.t2T, r2);
+        R wn = dot_(wc, F.nT), w1 = dot_(wc, F.t1T), w2 = dot_(wc, F.t2T);
+        R gn[8] = {F.nT[0], F.nT[1], F.nT[2], rn[0], rn[1], rn[2], sel == 1 ? wn : (R)0, sel == 2 ? wn : (R)0};
+        R g1[8] = {F.t1T[0], F.t1T[1], F.t1T[2], r1[0], r1[1], r1[2], sel == 1 ? w1 : (R)0, sel == 2 ? w1 : (R)0};
+        R g2[8] = {F.t2T[0], F.t2T[1], F.t2T[2], r2[0], r2[1], r2[2], sel == 1 ? w2 : (R)0, sel == 2 ? w2 : (R)0};
+        int mk = rows_into<0, 8>(H, rhs, gn, g1, g2, mu, D, An, Bt1, Bt2, first && meta_h(meta) != 17, meta_new(meta), x, cst);
+        st.set(s, 7, (R)meta_make(sel, mk, mk));
+      }
+      if constexpr (BLK) {
+        for (int c = 0; c < F.nfb; c++) {
+          int s = SLOT_BLOCK + c;
+          R r[3] = {st.get(s, 0), st.get(s, 1), st.get(s, 2)};
+          R An = st.get(s, 3), Bt1 = st.get(s, 4), Bt2 = st.get(s, 5), D = st.get(s, 6);
+          int meta = (int)st.get(s, 7);
+          R rn[3], r1[3], r2[3];
+          cross_(r, F.nB, rn); cross_(r, F.t1B, r1); cross_(r, F.t2B, r2);
+          R gn[6] = {F.nB[0], F.nB[1], F.nB[2], rn[0], rn[1], rn[2]};
+          R g1[6] = {F.t1B[0], F.t1B[1], F.t1B[2], r1[0], r1[1], r1[2]};
+          R g2[6] = {F.t2B[0], F.t2B[1], F.t2B[2], r2[0], r2[1], r2[2]};
+          int mk = rows_into<8, 6>(H, rhs, gn, g1, g2, P.cc[CC_BLOCK_FLOOR].mu, D, An, Bt1, Bt2, first && meta_h(meta) != 17, meta_new(meta), x, cst);
+          st.set(s, 7, (R)meta_make(3, mk, mk));
+        }
+        for (int c = 0; c < F.nc; c++) {
+          Coupled C;
+          coupled_load(P, st, F, c, C);
+          R g[3][14];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          R sg = (k & 1) ? -mu : mu;
+          for (int k = 0; k < 3; k++) {
+            R ct[3], cb[3];
+            cross_(C.rT, C.dT[k], ct);
+            cross_(C.rB, C.dB[k], cb);
+            R wk = dot_(C.wc, C.dT[k]);
 #pragma unroll
-          for (int i = 0; i < 6; i++) j[i] = gn[i] + sg * (k < 2 ? g1[i] : g2[i]);
-          add_row_block(H, j, (mk >> k) & 1 ? D : (R)0);
+            for (int i = 0; i < 3; i++) { g[k][i] = -C.dT[k][i]; g[k][3 + i] = -ct[i]; g[k][8 + i] = C.dB[k][i]; g[k][11 + i] = cb[i]; }
+            g[k][6] = C.sel == 1 ? -wk : (R)0;
+            g[k][7] = C.sel == 2 ? -wk : (R)0;
+          }
+          int mk = rows_into<0, 14>(H, rhs, g[0], g[1], g[2], C.mu, C.D, C.An, C.Bt1, C.Bt2, first && meta_h(C.meta) != 17, meta_new(C.meta), x, cst);
+          st.setc(c, 13, (R)meta_make(C.sel, mk, mk));
         }
       }
-      for (int c = 0; c < F.nc; c++) {
-        int s = SLOT_COUPLED + c;
-        Coupled C;
-        coupled_derive(P, st, F, S, s, C);
-        int meta = (int)st.get(s, 7), mk = meta_new(meta);
-        st.set(s, 7, (R)meta_make(C.sel, mk, mk));
-        R g[3][NV];
+      cost_x = cst;
+    }
+
+    // x: in = warm start, out = minimiser; fcon: out = J^T f at the minimiser
+    static BRS_HD void solve(const Params<R>& P, Store<R>& st, const Frame& F, R* x, const R* a0, R* fcon) {
+      R cost = 0;
+      bool first = true;
+      BRS_STAT(stats().solves[0]++; stats().last_iters[0] = 0);
+      for (int it = 0; it < 16; it++) {
+        R H[NHH], rhs[NN], xn[NN], ft[NN], c0, ct;
+        bool same;
+        BRS_STAT(stats().iters[0]++; stats().last_iters[0]++);
+        assemble(P, st, F, x, a0, first, H, rhs, c0);
+        if (first) cost = c0;
+        first = false;
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-          R ct[3], cb[3];
-          cross_(C.rT, C.dT[k], ct);
-          cross_(C.rB, C.dB[k], cb);
-          R wk = dot_(C.wc, C.dT[k]);
+        for (int i = 0; i < NN; i++) xn[i] = 0;
+        chol_solve_block<R, 0, NN>(H, rhs, xn);
+        passA(P, st, F, xn, a0, ct, ft, same);
+        bool full = true;
+        // pure active-set iteration for the first sweeps (it terminates at once in ~97% of the substeps); if it has not
+        // settled by then, fall back to cost-monotone damping, which cannot cycle
+        for (int bt = 0; it >= BRS_UNDAMPED_ITERS && bt < 6 && ct > cost + (R)1e-5 * abs_(cost) + (R)1e-12; bt++) {
+          full = false;
+          BRS_STAT(stats().backtracks[0]++);
 #pragma unroll
-          for (int i = 0; i < 3; i++) { g[k][i] = -C.dT[k][i]; g[k][3 + i] = -ct[i]; g[k][8 + i] = C.dB[k][i]; g[k][11 + i] = cb[i]; }
-          g[k][6] = C.sel == 1 ? -wk : (R)0;
-          g[k][7] = C.sel == 2 ? -wk : (R)0;
+          for (int i = 0; i < NN; i++) xn[i] = x[i] + (R)0.5 * (xn[i] - x[i]);
+          passA(P, st, F, xn, a0, ct, ft, same);
         }
-        R j[NV];
+        cost = ct;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          R sg = (k & 1) ? -C.mu : C.mu;
-#pragma unroll
-          for (int i = 0; i < NV; i++) j[i] = g[0][i] + sg * (k < 2 ? g[1][i] : g[2][i]);
-          add_row(H, j, (mk >> k) & 1 ? C.D : (R)0);
-        }
-        coupled = true;
+        for (int i = 0; i < NN; i++) { x[i] = xn[i]; fcon[i] = ft[i]; }
+        if (same && full) break;
       }
     }
-    R ng[NV];
-#pragma unroll
-    for (int i = 0; i < NV; i++) { ng[i] = -grad[i]; dir[i] = 0; }
-    if constexpr (BLK) {
-      if (coupled) chol_solve_block<R, 0, NV>(H, ng, dir);
-      else {
-        chol_solve_block<R, 0, 8>(H, ng, dir);
-        chol_solve_block<R, 8, NV>(H, ng, dir);
-      }
-    } else
-      chol_solve_block<R, 0, 8>(H, ng, dir);
-  }
+  };
 
   // ---- the substep
   static BRS_HD void substep(const Params<R>& P, Store<R>& st, ES& S, R ctrlL, R ctrlR) {
@@ -911,6 +974,7 @@ template <typename R, bool BLK> struct Sim {
     msolve0_(P, f, F.a0);
     // collision: robot <-> floor.  Slot priority: wheel main points, torso corners, wheel triangle points
     F.nfr = 0; F.nfb = 0; F.nc = 0;
+    F.pnfr = S.pnfr; F.pnfb = S.pnfb; F.pnc = S.pnc;
     collide_wheel(P, st, F, u, S.w, S.ww, zT, 1, false);
     collide_wheel(P, st, F, u, S.w, S.ww, zT, 2, false);
     collide_torso(P, st, F, u, S.w, S.ww, zT);
@@ -934,52 +998,18 @@ template <typename R, bool BLK> struct Sim {
         F.a0[11 + i] = 0;
       }
       collide_block_floor(P, st, F, uB, S.bw, zB);
-      collide_coupled(P, st, F);
+#ifndef BRS_NO_COUPLED
+      collide_coupled(P, st, F, S);
+#endif
     }
+    S.pnfr = F.nfr; S.pnfb = F.nfb; S.pnc = F.nc;
     // constraint solve
     R fcon[NV];
     if (F.nfr + F.nfb + F.nc == 0) {
 #pragma unroll
       for (int i = 0; i < NV; i++) { S.a[i] = F.a0[i]; fcon[i] = 0; }
-    } else {
-      R x[NV], grad[NV], cost;
-      bool same;
-#pragma unroll
-      for (int i = 0; i < NV; i++) x[i] = S.a[i];
-      // a body without contacts: its unconstrained acceleration is exact
-      if (F.nc == 0 && F.nfr == 0) {
-#pragma unroll
-        for (int i = 0; i < 8; i++) x[i] = F.a0[i];
-      }
-      if constexpr (BLK) {
-        if (F.nc == 0 && F.nfb == 0) {
-#pragma unroll
-          for (int i = 8; i < NV; i++) x[i] = F.a0[i];
-        }
-      }
-      passA(P, st, F, S, x, cost, grad, fcon, same);
-      for (int it = 0; it < 12; it++) {
-        R dir[NV], xt[NV], gt[NV], ft[NV], ct;
-        bool st_same;
-        newton_dir(P, st, F, S, grad, dir);
-#pragma unroll
-        for (int i = 0; i < NV; i++) xt[i] = x[i] + dir[i];
-        passA(P, st, F, S, xt, ct, gt, ft, st_same);
-        bool full = true;
-        for (int bt = 0; bt < 6 && ct > cost + (R)1e-5 * abs_(cost) + (R)1e-12; bt++) {
-          full = false;
-#pragma unroll
-          for (int i = 0; i < NV; i++) { dir[i] *= (R)0.5; xt[i] = x[i] + dir[i]; }
-          passA(P, st, F, S, xt, ct, gt, ft, st_same);
-        }
-        cost = ct;
-#pragma unroll
-        for (int i = 0; i < NV; i++) { x[i] = xt[i]; grad[i] = gt[i]; fcon[i] = ft[i]; }
-        if (st_same && full) break;
-      }
-#pragma unroll
-      for (int i = 0; i < NV; i++) S.a[i] = x[i];
-    }
+    } else
+      Solver::solve(P, st, F, S.a, F.a0, fcon);
     // implicitfast: (M + h*diag(damping + kv[unclamped])) acc = smooth + constraint
     R rhs[8], acc[8];
 #pragma unroll

@@ -26,11 +26,11 @@ using namespace brs;
 
 namespace {
 
-template <bool BLK> constexpr int nslots() { return BLK ? N_SLOTS_ENV03 : N_SLOTS_ENV01; }
+template <bool BLK> constexpr int lane_words() { return BLK ? LDS_WORDS_ENV03 : LDS_WORDS_ENV01; }
 
 template <bool BLK> __device__ __forceinline__ Store<float> lane_store(float* lds) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  return Store<float>{lds + wave * (64 * nslots<BLK>() * SLOT_WORDS) + lane, 64};
+  return Store<float>{lds + wave * (64 * lane_words<BLK>()) + lane, 64};
 }
 
 template <bool BLK>
@@ -143,7 +143,7 @@ int fail(brs_handle* h, int code, const std::string& msg) {
     if (e_ != hipSuccess) return fail(h, BRS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
   } while (0)
 
-size_t lds_bytes(const brs_handle* h) { return (size_t)h->bt * (h->blk ? N_SLOTS_ENV03 : N_SLOTS_ENV01) * SLOT_WORDS * sizeof(float); }
+size_t lds_bytes(const brs_handle* h) { return (size_t)h->bt * (h->blk ? LDS_WORDS_ENV03 : LDS_WORDS_ENV01) * sizeof(float); }
 int grid_of(const brs_handle* h) { return (h->N + h->bt - 1) / h->bt; }
 
 template <bool BLK> int upload_state(brs_handle* h, const std::vector<double>& d, const std::vector<float>& f, const std::vector<int>& ii) {

@@ -60,6 +60,7 @@ BRS_HD void load_state(EnvState<R, BLK>& S, const double* d, const FT* f, const 
   S.rng_ctr = (uint32_t)ii[L::I_RNG * N + i];
   S.side_front = ii[L::I_SIDE * N + i];
   S.bad = ii[L::I_BAD * N + i];
+  S.pnfr = 0; S.pnfb = 0; S.pnc = 0;
 }
 
 template <typename R, bool BLK, typename FT>

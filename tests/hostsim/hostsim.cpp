@@ -61,7 +61,7 @@ template <typename R, bool BLK> struct HostSim : IHost {
   }
   void close_stream(Stream<R>& rng, ES& S, size_t i) { S.rng_ctr = rng.ctr; spos[i] = rng.script_pos; }
   void physics(const double* ctrl, int nsub) override {
-    R buf[N_SLOTS_ENV03 * SLOT_WORDS];
+    R buf[LDS_WORDS_ENV03];
     for (size_t i = 0; i < N; i++) {
       ES S;
       load_state<R, BLK>(S, d.data(), f.data(), ii.data(), N, i);
@@ -87,7 +87,7 @@ template <typename R, bool BLK> struct HostSim : IHost {
     }
   }
   void step(const float* act, float* obs, float* rew, uint8_t* term, uint8_t* trunc, float* tobs) override {
-    R buf[N_SLOTS_ENV03 * SLOT_WORDS];
+    R buf[LDS_WORDS_ENV03];
     for (size_t i = 0; i < N; i++) {
       ES S;
       load_state<R, BLK>(S, d.data(), f.data(), ii.data(), N, i);
@@ -107,7 +107,7 @@ template <typename R, bool BLK> struct HostSim : IHost {
   int script_remaining(int env) const override { return (int)scripts[env].size() - spos[env]; }
   void contact_counts(int env, const double* ctrl, int* out) override {
     // one throw-away substep on a copy, to look at the contact list sizes
-    R buf[N_SLOTS_ENV03 * SLOT_WORDS];
+    R buf[LDS_WORDS_ENV03];
     ES S;
     load_state<R, BLK>(S, d.data(), f.data(), ii.data(), N, env);
     Store<R> st{buf, 1};
