@@ -1139,20 +1139,15 @@ template <typename R, bool BLK> struct Sim {
     get_obs(P, S, rng, true, obs);
   }
 
-  // one full env step; obs/terminal_obs are 6 floats
-  static BRS_HD void env_step(const Params<R>& P, Store<R>& st, ES& S, Stream<R>& rng, float a0, float a1, float* obs,
-                              float* terminal_obs, float& reward, int& terminated, int& truncated) {
+  // ---- one full env step = env_pre (reward + control law on the PRE-step state) -> nsub substeps -> env_post
+  static BRS_HD R env_pre(const Params<R>& P, const ES& S, Stream<R>& rng, float a0, float a1, R& ctrlL, R& ctrlR) {
     R rew = get_reward(P, S, rng);
-    R ctrlL = S.ww[0] + (R)a0 * (R)4, ctrlR = S.ww[1] + (R)a1 * (R)4;
-    for (int k = 0; k < P.nsub; k++) {
-      if (k == P.nsub - 1) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) S.xq[i] = S.q[i];
-#pragma unroll
-        for (int i = 0; i < 3; i++) S.xp[i] = S.p[i];
-      }
-      substep(P, st, S, ctrlL, ctrlR);
-    }
+    ctrlL = S.ww[0] + (R)a0 * (R)4;  // envs/env01_v2.py:31-36 ; the env does not clip the action
+    ctrlR = S.ww[1] + (R)a1 * (R)4;
+    return rew;
+  }
+  static BRS_HD void env_post(const Params<R>& P, ES& S, Stream<R>& rng, R rew, float* obs, float* terminal_obs, float& reward,
+                              int& terminated, int& truncated) {
     // mj_check*: NaN / runaway -> reset the simulation (counted)
     bool bad = !(S.p[0] == S.p[0]) || !(S.q[0] == S.q[0]) || !(S.v[0] == S.v[0]) || abs_(S.v[0]) > (R)1e10 ||
                abs_(S.v[2]) > (R)1e10 || !(S.ww[0] == S.ww[0]);
@@ -1162,7 +1157,7 @@ template <typename R, bool BLK> struct Sim {
       S.bad++;
       env_reset(P, S, rng, tmp);
     }
-    if constexpr (BLK) {
+    if constexpr (BLK) {  // envs/env03_v1.py:39-49
       R bv2 = S.bv[0] * S.bv[0] + S.bv[1] * S.bv[1] + S.bv[2] * S.bv[2];
       if (bv2 < (R)0.01 && S.block_timer < 0) {
         S.bp[0] = 10; S.bp[1] = 10; S.bp[2] = 0;
@@ -1182,6 +1177,21 @@ template <typename R, bool BLK> struct Sim {
 #pragma unroll
     for (int i = 0; i < 6; i++) terminal_obs[i] = obs[i];
     if (P.auto_reset && (terminated || truncated)) env_reset(P, S, rng, obs);
+  }
+  static BRS_HD void env_step(const Params<R>& P, Store<R>& st, ES& S, Stream<R>& rng, float a0, float a1, float* obs,
+                              float* terminal_obs, float& reward, int& terminated, int& truncated) {
+    R ctrlL, ctrlR;
+    R rew = env_pre(P, S, rng, a0, a1, ctrlL, ctrlR);
+    for (int k = 0; k < P.nsub; k++) {
+      if (k == P.nsub - 1) {  // accessor pose = kinematics of the LAST forward pass (lags qpos by one substep)
+#pragma unroll
+        for (int i = 0; i < 4; i++) S.xq[i] = S.q[i];
+#pragma unroll
+        for (int i = 0; i < 3; i++) S.xp[i] = S.p[i];
+      }
+      substep(P, st, S, ctrlL, ctrlR);
+    }
+    env_post(P, S, rng, rew, obs, terminal_obs, reward, terminated, truncated);
   }
 };
 

@@ -23,6 +23,8 @@ struct IHost {
   virtual void physics(const double* ctrl, int nsub) = 0;
   virtual void reset(const uint8_t* mask, float* obs) = 0;
   virtual void step(const float* act, float* obs, float* rew, uint8_t* term, uint8_t* trunc, float* tobs) = 0;
+  virtual void step_stub(int env, const float* act, const double* qpos, const double* qvel, const double* xquat, const double* xpos,
+                         float* obs, float* rew, uint8_t* term, uint8_t* trunc, double* ctrl) = 0;
   virtual void script(int env, const double* u, int n) = 0;
   virtual int script_remaining(int env) const = 0;
   virtual void contact_counts(int env, const double* ctrl, int* out) = 0;
@@ -103,6 +105,43 @@ template <typename R, bool BLK> struct HostSim : IHost {
       store_state<R, BLK>(S, d.data(), f.data(), ii.data(), N, i);
     }
   }
+  // physics replaced by a scripted post-step state, exactly like tools/gen_golden.py's stubbed mj_step
+  void step_stub(int env, const float* act, const double* qpos, const double* qvel, const double* xquat, const double* xpos,
+                 float* obs, float* rew, uint8_t* term, uint8_t* trunc, double* ctrl) override {
+    size_t i = env;
+    ES S;
+    load_state<R, BLK>(S, d.data(), f.data(), ii.data(), N, i);
+    Stream<R> rng;
+    open_stream(rng, S, i);
+    R cl, cr;
+    R r = Sim<R, BLK>::env_pre(P, S, rng, act[0], act[1], cl, cr);
+    ctrl[0] = (double)cl; ctrl[1] = (double)cr;
+    close_stream(rng, S, i);
+    store_state<R, BLK>(S, d.data(), f.data(), ii.data(), N, i);
+    // install the post state (row i only) through the same conversion the C ABI uses
+    std::vector<double> qp((size_t)L::NQ * N), qv((size_t)L::NV * N), tm(N);
+    hostconv::get_state<BLK>(d.data(), f.data(), N, qp.data(), qv.data(), nullptr, tm.data());
+    for (int k = 0; k < L::NQ; k++) qp[i * L::NQ + k] = qpos[k];
+    for (int k = 0; k < L::NV; k++) qv[i * L::NV + k] = qvel[k];
+    for (int k = 0; k < P.nsub; k++) tm[i] += P.h_d;
+    std::vector<double> xq(4 * N), xp(3 * N);
+    hostconv::get_xpose<BLK>(d.data(), N, xq.data(), xp.data());
+    // note: set_state normalises quaternions; the block orientation golden is compared sign/scale-insensitively
+    std::vector<double> dsave = d;
+    hostconv::set_state<BLK>(d.data(), f.data(), N, qp.data(), qv.data(), nullptr, tm.data());
+    for (size_t e = 0; e < N; e++) if (e != i) { for (int k = 0; k < 4; k++) xq[4 * e + k] = dsave[(L::D_XQ + k) * N + e]; for (int k = 0; k < 3; k++) xp[3 * e + k] = dsave[(L::D_XP + k) * N + e]; }
+    for (int k = 0; k < 4; k++) xq[4 * i + k] = xquat[k];
+    for (int k = 0; k < 3; k++) xp[3 * i + k] = xpos[k];
+    hostconv::set_xpose<BLK>(d.data(), N, xq.data(), xp.data());
+    load_state<R, BLK>(S, d.data(), f.data(), ii.data(), N, i);
+    open_stream(rng, S, i);
+    int te, tr;
+    float tob[6];
+    Sim<R, BLK>::env_post(P, S, rng, r, obs, tob, *rew, te, tr);
+    *term = (uint8_t)te; *trunc = (uint8_t)tr;
+    close_stream(rng, S, i);
+    store_state<R, BLK>(S, d.data(), f.data(), ii.data(), N, i);
+  }
   void script(int env, const double* u, int n) override { scripts[env].assign(u, u + n); spos[env] = 0; }
   int script_remaining(int env) const override { return (int)scripts[env].size() - spos[env]; }
   void contact_counts(int env, const double* ctrl, int* out) override {
@@ -139,6 +178,8 @@ void hs_set_xpose(void* h, const double* a, const double* b) { ((IHost*)h)->set_
 void hs_physics(void* h, const double* ctrl, int nsub) { ((IHost*)h)->physics(ctrl, nsub); }
 void hs_reset(void* h, const uint8_t* m, float* obs) { ((IHost*)h)->reset(m, obs); }
 void hs_step(void* h, const float* a, float* o, float* r, uint8_t* te, uint8_t* tr, float* to) { ((IHost*)h)->step(a, o, r, te, tr, to); }
+void hs_step_stub(void* h, int e, const float* a, const double* qp, const double* qv, const double* xq, const double* xp, float* o, float* r,
+                  uint8_t* te, uint8_t* tr, double* ctrl) { ((IHost*)h)->step_stub(e, a, qp, qv, xq, xp, o, r, te, tr, ctrl); }
 void hs_script(void* h, int e, const double* u, int n) { ((IHost*)h)->script(e, u, n); }
 int hs_script_remaining(void* h, int e) { return ((IHost*)h)->script_remaining(e); }
 }

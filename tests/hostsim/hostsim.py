@@ -23,7 +23,7 @@ def lib():
                                hs_get_state=[vp, dp, dp, dp, dp], hs_get_aux=[vp, dp], hs_set_aux=[vp, dp],
                                hs_get_xpose=[vp, dp, dp], hs_set_xpose=[vp, dp, dp], hs_physics=[vp, dp, C.c_int],
                                hs_reset=[vp, u8p, fp], hs_step=[vp, fp, fp, fp, u8p, u8p, fp],
-                               hs_script=[vp, C.c_int, dp, C.c_int], hs_script_remaining=[vp, C.c_int]).items():
+                               hs_script=[vp, C.c_int, dp, C.c_int], hs_step_stub=[vp, C.c_int, fp, dp, dp, dp, dp, fp, fp, u8p, u8p, dp], hs_script_remaining=[vp, C.c_int]).items():
             getattr(L, name).argtypes = args
         _lib = L
     return _lib
@@ -97,6 +97,17 @@ class HostSim:
         rew = np.zeros(self.n, np.float32); te = np.zeros(self.n, np.uint8); tr = np.zeros(self.n, np.uint8)
         self.L.hs_step(self.h, _p(a, C.c_float), _p(obs, C.c_float), _p(rew, C.c_float), _p(te, C.c_uint8), _p(tr, C.c_uint8), _p(tob, C.c_float))
         return obs, rew, te.astype(bool), tr.astype(bool), tob
+
+    def step_stub(self, env, action, qpos, qvel, xquat, xpos):
+        c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        a = np.ascontiguousarray(action, dtype=np.float32)
+        qpos, qvel, xquat, xpos = c(qpos), c(qvel), c(xquat), c(xpos)
+        obs = np.zeros(6, np.float32); rew = np.zeros(1, np.float32); te = np.zeros(1, np.uint8); tr = np.zeros(1, np.uint8)
+        ctrl = np.zeros(2)
+        self.L.hs_step_stub(self.h, env, _p(a, C.c_float), _p(qpos, C.c_double), _p(qvel, C.c_double), _p(xquat, C.c_double),
+                            _p(xpos, C.c_double), _p(obs, C.c_float), _p(rew, C.c_float), _p(te, C.c_uint8), _p(tr, C.c_uint8),
+                            _p(ctrl, C.c_double))
+        return obs, float(rew[0]), bool(te[0]), bool(tr[0]), ctrl
 
     def script_uniforms(self, env, u):
         u = np.ascontiguousarray(u, dtype=np.float64)
