@@ -294,6 +294,80 @@ template <typename R, int N0, int N1> BRS_HD void chol_solve_block(R* H, const R
   }
 }
 
+// ------------------------------------------------------------------------------------ packed pairs
+// A lone wave per SIMD issues one VALU instruction every ~4 cycles whether it is v_fma_f32 or v_pk_fma_f32
+// (tools/microbench/issue_rate.hip: packed = 1.6x the FMA rate), so the dense per-lane algebra is written on
+// pairs: on the GPU V2<float> is a 2-wide ext vector (-> v_pk_fma_f32 / v_pk_mul_f32), on the host a plain struct.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef float brs_f2 __attribute__((ext_vector_type(2)));
+template <typename R> struct V2T { struct type { R x, y; }; };
+template <> struct V2T<float> { typedef brs_f2 type; };
+#else
+template <typename R> struct V2T { struct type { R x, y; }; };
+#endif
+template <typename R> using V2 = typename V2T<R>::type;
+template <typename R> BRS_HD V2<R> v2_make(R a, R b) { V2<R> v; v.x = a; v.y = b; return v; }
+template <typename R> BRS_HD V2<R> v2_splat(R a) { V2<R> v; v.x = a; v.y = a; return v; }
+#if defined(__HIP_DEVICE_COMPILE__)
+BRS_HD brs_f2 v2_fma(brs_f2 a, brs_f2 b, brs_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+BRS_HD brs_f2 v2_mul(brs_f2 a, brs_f2 b) { return a * b; }
+#endif
+template <typename V> BRS_HD V v2_fma(V a, V b, V c) { V r; r.x = a.x * b.x + c.x; r.y = a.y * b.y + c.y; return r; }
+template <typename V> BRS_HD V v2_mul(V a, V b) { V r; r.x = a.x * b.x; r.y = a.y * b.y; return r; }
+
+// packed lower triangle: row a holds the pairs (cols 2k, 2k+1), k = 0..a/2; for even a the last .y is padding
+BRS_HD constexpr int hp(int a, int k) { return (a / 2) * (a / 2 + 1) + ((a & 1) ? (a / 2 + 1) : 0) + k; }
+BRS_HD constexpr int hp_count(int n) { return hp(n - 1, (n - 1) / 2) + 1; }
+#define BRS_H2(a, b) (((b) & 1) ? H[hp((a), (b) / 2)].y : H[hp((a), (b) / 2)].x)
+template <typename V, typename R> BRS_HD void h2_set(V* H, int a, int b, R v) {
+  if (b & 1) H[hp(a, b / 2)].y = v; else H[hp(a, b / 2)].x = v;
+}
+
+// in-place Cholesky H = L L^T on the packed-pair layout and solve H x = b.  Row dot products run on pairs.
+template <typename R, int N> BRS_HD void chol_solve_packed(V2<R>* H, const R* b, R* x) {
+  R dinv[N];
+#pragma unroll
+  for (int j = 0; j < N; j++) {
+    // s = H[j][j] - sum_{k<j} L[j][k]^2
+    V2<R> acc = v2_splat<R>((R)0);
+#pragma unroll
+    for (int kp = 0; kp < j / 2; kp++) acc = v2_fma(H[hp(j, kp)], H[hp(j, kp)], acc);
+    R s = BRS_H2(j, j) - (acc.x + acc.y);
+    if (j & 1) s -= H[hp(j, j / 2)].x * H[hp(j, j / 2)].x;
+    s = max_(s, (R)1e-30);
+    R inv = rsqrt_(s);
+    dinv[j] = inv;
+#pragma unroll
+    for (int i = j + 1; i < N; i++) {
+      V2<R> a2 = v2_splat<R>((R)0);
+#pragma unroll
+      for (int kp = 0; kp < j / 2; kp++) a2 = v2_fma(H[hp(i, kp)], H[hp(j, kp)], a2);
+      R t = BRS_H2(i, j) - (a2.x + a2.y);
+      if (j & 1) t -= H[hp(i, j / 2)].x * H[hp(j, j / 2)].x;
+      if (j & 1) H[hp(i, j / 2)].y = t * inv; else H[hp(i, j / 2)].x = t * inv;
+    }
+  }
+  // forward substitution on pairs of y
+  V2<R> y2[(N + 1) / 2];
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    V2<R> a2 = v2_splat<R>((R)0);
+#pragma unroll
+    for (int kp = 0; kp < i / 2; kp++) a2 = v2_fma(H[hp(i, kp)], y2[kp], a2);
+    R sv = b[i] - (a2.x + a2.y);
+    if (i & 1) sv -= H[hp(i, i / 2)].x * y2[i / 2].x;
+    if (i & 1) y2[i / 2].y = sv * dinv[i]; else y2[i / 2].x = sv * dinv[i];
+  }
+  // backward substitution (column access: scalar)
+#pragma unroll
+  for (int i = N - 1; i >= 0; i--) {
+    R sv = (i & 1) ? y2[i / 2].y : y2[i / 2].x;
+#pragma unroll
+    for (int k = i + 1; k < N; k++) sv -= BRS_H2(k, i) * x[k];
+    x[i] = sv * dinv[i];
+  }
+}
+
 // ------------------------------------------------------------------------------------ one substep
 template <typename R, bool BLK> struct Sim {
   static constexpr int NV = BLK ? 14 : 8;
@@ -804,57 +878,69 @@ template <typename R, bool BLK> struct Sim {
       same = sm;
     }
 
-    // the 4 pyramid rows of one contact into H (dofs A0..A0+NA) and rhs; on `first` the rows are evaluated at x
-    template <int A0, int NA>
-    static BRS_HD int rows_into(R* H, R* rhs, const R* gn, const R* g1, const R* g2, R mu, R D, R An, R Bt1, R Bt2,
-                                bool eval, int mnew, const R* x, R& cst) {
-      int mk = 0;
+    static constexpr int NP = (NN + 1) / 2, NH2 = hp_count(NN);
+
+    // One contact into H and rhs through its 3x3 weight matrix in the contact frame:
+    //   rows j_k = G_n +- mu G_t ;  sum_k act_k D j_k j_k^T = G^T W G ,  W = D [[sum a, mu(a0-a1), mu(a2-a3)], [., mu^2(a0+a1), 0], [., 0, mu^2(a2+a3)]]
+    // G rows arrive as pairs over the dof range [2*P0, 2*(P0+NPA)); `eval`: decide the active rows at x (else from mnew).
+    template <int P0, int NPA>
+    static BRS_HD int contact_into(V2<R>* H, V2<R>* rhs2, const V2<R>* gn, const V2<R>* g1, const V2<R>* g2, R mu, R D, R An,
+                                   R Bt1, R Bt2, bool eval, int mnew, const V2<R>* x2) {
+      int mk = mnew;
+      if (eval) {
+        V2<R> an = v2_splat<R>((R)0), a1 = an, a2 = an;
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        R sg = (k & 1) ? -mu : mu;
-        R j[NA];
+        for (int k = 0; k < NPA; k++) { an = v2_fma(gn[k], x2[P0 + k], an); a1 = v2_fma(g1[k], x2[P0 + k], a1); a2 = v2_fma(g2[k], x2[P0 + k], a2); }
+        R cn = (an.x + an.y) - An, c1 = mu * (a1.x + a1.y) - Bt1, c2 = mu * (a2.x + a2.y) - Bt2;
+        mk = (cn + c1 < 0 ? 1 : 0) | (cn - c1 < 0 ? 2 : 0) | (cn + c2 < 0 ? 4 : 0) | (cn - c2 < 0 ? 8 : 0);
+      }
+      R b0 = (mk & 1) ? (R)1 : (R)0, b1 = (mk & 2) ? (R)1 : (R)0, b2 = (mk & 4) ? (R)1 : (R)0, b3 = (mk & 8) ? (R)1 : (R)0;
+      R Dm = D * mu, Dmm = Dm * mu;
+      R Wnn = D * (b0 + b1 + b2 + b3), Wn1 = Dm * (b0 - b1), Wn2 = Dm * (b2 - b3), W11 = Dmm * (b0 + b1), W22 = Dmm * (b2 + b3);
+      // rhs += sum_k act_k D aref_k j_k with aref = An +- Bt1, An +- Bt2
+      R rn = Wnn * An + D * ((b0 - b1) * Bt1 + (b2 - b3) * Bt2);
+      R r1 = Wn1 * An + Dm * (b0 + b1) * Bt1, r2 = Wn2 * An + Dm * (b2 + b3) * Bt2;
+      V2<R> tn[NPA], t1[NPA], t2[NPA];
+      const V2<R> sWnn = v2_splat(Wnn), sWn1 = v2_splat(Wn1), sWn2 = v2_splat(Wn2), sW11 = v2_splat(W11), sW22 = v2_splat(W22);
+      const V2<R> srn = v2_splat(rn), sr1 = v2_splat(r1), sr2 = v2_splat(r2);
 #pragma unroll
-        for (int i = 0; i < NA; i++) j[i] = gn[i] + sg * (k < 2 ? g1[i] : g2[i]);
-        R aref = An + ((k & 1) ? (R)-1 : (R)1) * (k < 2 ? Bt1 : Bt2);
-        bool act;
-        if (eval) {
-          R e = -aref;
+      for (int k = 0; k < NPA; k++) {
+        tn[k] = v2_fma(sWnn, gn[k], v2_fma(sWn1, g1[k], v2_mul(sWn2, g2[k])));
+        t1[k] = v2_fma(sWn1, gn[k], v2_mul(sW11, g1[k]));
+        t2[k] = v2_fma(sWn2, gn[k], v2_mul(sW22, g2[k]));
+        rhs2[P0 + k] = v2_fma(srn, gn[k], v2_fma(sr1, g1[k], v2_fma(sr2, g2[k], rhs2[P0 + k])));
+      }
 #pragma unroll
-          for (int i = 0; i < NA; i++) e += j[i] * x[A0 + i];
-          act = e < 0;
-        } else
-          act = (mnew >> k) & 1;
-        mk |= act ? (1 << k) : 0;
-        R Dk = act ? D : (R)0, da = Dk * aref;
+      for (int a = 0; a < 2 * NPA; a++) {
+        const R ga = (a & 1) ? gn[a / 2].y : gn[a / 2].x, gb = (a & 1) ? g1[a / 2].y : g1[a / 2].x, gc = (a & 1) ? g2[a / 2].y : g2[a / 2].x;
+        const V2<R> sa = v2_splat(ga), sb = v2_splat(gb), sc = v2_splat(gc);
 #pragma unroll
-        for (int a = 0; a < NA; a++) {
-          R dj = Dk * j[a];
-          rhs[A0 + a] += da * j[a];
-#pragma unroll
-          for (int b = 0; b <= a; b++) H[tri(A0 + a, A0 + b)] += dj * j[b];
-        }
+        for (int k = 0; k <= a / 2; k++)
+          H[hp(2 * P0 + a, P0 + k)] = v2_fma(sa, tn[k], v2_fma(sb, t1[k], v2_fma(sc, t2[k], H[hp(2 * P0 + a, P0 + k)])));
       }
       return mk;
     }
 
-    // assemble H = M + sum_active D j j^T and rhs = M a0 + sum_active D aref j; cost_x = cost at x (only on `first`)
-    static BRS_HD void assemble(const Params<R>& P, Store<R>& st, const Frame& F, const R* x, const R* a0, bool first, R* H,
-                                R* rhs, R& cost_x) {
+    // assemble H = M + sum_active D j j^T and rhs = M a0 + sum_active D aref j  (both on the packed-pair layout)
+    static BRS_HD void assemble(const Params<R>& P, Store<R>& st, const Frame& F, const R* x, const R* a0, bool first,
+                                V2<R>* H, V2<R>* rhs2) {
 #pragma unroll
-      for (int i = 0; i < NHH; i++) H[i] = 0;
-      H[tri(0, 0)] = P.m; H[tri(1, 1)] = P.m; H[tri(2, 2)] = P.m;
-      H[tri(3, 3)] = P.Ixx; H[tri(4, 4)] = P.Iyy; H[tri(5, 5)] = P.Izz; H[tri(6, 6)] = P.Ia; H[tri(7, 7)] = P.Ia;
-      H[tri(4, 0)] = P.mcz; H[tri(3, 1)] = -P.mcz; H[tri(6, 3)] = -P.Ia; H[tri(7, 3)] = P.Ia;
+      for (int i = 0; i < NH2; i++) H[i] = v2_splat<R>((R)0);
+      h2_set(H, 0, 0, P.m); h2_set(H, 1, 1, P.m); h2_set(H, 2, 2, P.m);
+      h2_set(H, 3, 3, P.Ixx); h2_set(H, 4, 4, P.Iyy); h2_set(H, 5, 5, P.Izz); h2_set(H, 6, 6, P.Ia); h2_set(H, 7, 7, P.Ia);
+      h2_set(H, 4, 0, P.mcz); h2_set(H, 3, 1, -P.mcz); h2_set(H, 6, 3, -P.Ia); h2_set(H, 7, 3, P.Ia);
+      R rhs[NN];
       mmul_(P, a0, rhs);
       if constexpr (BLK) {
 #pragma unroll
         for (int i = 0; i < 3; i++) {
-          H[tri(8 + i, 8 + i)] = P.mB; H[tri(11 + i, 11 + i)] = P.IB;
+          h2_set(H, 8 + i, 8 + i, P.mB); h2_set(H, 11 + i, 11 + i, P.IB);
           rhs[8 + i] = P.mB * a0[8 + i]; rhs[11 + i] = P.IB * a0[11 + i];
         }
       }
-      R cst = 0;
-      if (first) { R Md[NN]; gauss(P, x, a0, Md, cst); }
+      V2<R> x2[NP];
+#pragma unroll
+      for (int k = 0; k < NP; k++) { x2[k] = v2_make(x[2 * k], x[2 * k + 1]); rhs2[k] = v2_make(rhs[2 * k], rhs[2 * k + 1]); }
       for (int c = 0; c < F.nfr; c++) {
         int s = SLOT_ROBOT + c;
         R r[3] = {st.get(s, 0), st.get(s, 1), st.get(s, 2)};
@@ -865,10 +951,11 @@ template <typename R, bool BLK> struct Sim {
         wheel_col(P, sel, r, wc);
         cross_(r, F.nT, rn); cross_(r, F.t1T, r1); cross_(r, F.t2T, r2);
         R wn = dot_(wc, F.nT), w1 = dot_(wc, F.t1T), w2 = dot_(wc, F.t2T);
-        R gn[8] = {F.nT[0], F.nT[1], F.nT[2], rn[0], rn[1], rn[2], sel == 1 ? wn : (R)0, sel == 2 ? wn : (R)0};
-        R g1[8] = {F.t1T[0], F.t1T[1], F.t1T[2], r1[0], r1[1], r1[2], sel == 1 ? w1 : (R)0, sel == 2 ? w1 : (R)0};
-        R g2[8] = {F.t2T[0], F.t2T[1], F.t2T[2], r2[0], r2[1], r2[2], sel == 1 ? w2 : (R)0, sel == 2 ? w2 : (R)0};
-        int mk = rows_into<0, 8>(H, rhs, gn, g1, g2, mu, D, An, Bt1, Bt2, first && meta_h(meta) != 17, meta_new(meta), x, cst);
+        R zL = sel == 1 ? (R)1 : (R)0, zR = sel == 2 ? (R)1 : (R)0;
+        V2<R> gn[4] = {v2_make(F.nT[0], F.nT[1]), v2_make(F.nT[2], rn[0]), v2_make(rn[1], rn[2]), v2_make(zL * wn, zR * wn)};
+        V2<R> g1[4] = {v2_make(F.t1T[0], F.t1T[1]), v2_make(F.t1T[2], r1[0]), v2_make(r1[1], r1[2]), v2_make(zL * w1, zR * w1)};
+        V2<R> g2[4] = {v2_make(F.t2T[0], F.t2T[1]), v2_make(F.t2T[2], r2[0]), v2_make(r2[1], r2[2]), v2_make(zL * w2, zR * w2)};
+        int mk = contact_into<0, 4>(H, rhs2, gn, g1, g2, mu, D, An, Bt1, Bt2, first && meta_h(meta) != 17, meta_new(meta), x2);
         st.set(s, 7, (R)meta_make(sel, mk, mk));
       }
       if constexpr (BLK) {
@@ -879,32 +966,32 @@ template <typename R, bool BLK> struct Sim {
           int meta = (int)st.get(s, 7);
           R rn[3], r1[3], r2[3];
           cross_(r, F.nB, rn); cross_(r, F.t1B, r1); cross_(r, F.t2B, r2);
-          R gn[6] = {F.nB[0], F.nB[1], F.nB[2], rn[0], rn[1], rn[2]};
-          R g1[6] = {F.t1B[0], F.t1B[1], F.t1B[2], r1[0], r1[1], r1[2]};
-          R g2[6] = {F.t2B[0], F.t2B[1], F.t2B[2], r2[0], r2[1], r2[2]};
-          int mk = rows_into<8, 6>(H, rhs, gn, g1, g2, P.cc[CC_BLOCK_FLOOR].mu, D, An, Bt1, Bt2, first && meta_h(meta) != 17, meta_new(meta), x, cst);
+          V2<R> gn[3] = {v2_make(F.nB[0], F.nB[1]), v2_make(F.nB[2], rn[0]), v2_make(rn[1], rn[2])};
+          V2<R> g1[3] = {v2_make(F.t1B[0], F.t1B[1]), v2_make(F.t1B[2], r1[0]), v2_make(r1[1], r1[2])};
+          V2<R> g2[3] = {v2_make(F.t2B[0], F.t2B[1]), v2_make(F.t2B[2], r2[0]), v2_make(r2[1], r2[2])};
+          int mk = contact_into<4, 3>(H, rhs2, gn, g1, g2, P.cc[CC_BLOCK_FLOOR].mu, D, An, Bt1, Bt2, first && meta_h(meta) != 17,
+                                      meta_new(meta), x2);
           st.set(s, 7, (R)meta_make(3, mk, mk));
         }
         for (int c = 0; c < F.nc; c++) {
           Coupled C;
           coupled_load(P, st, F, c, C);
-          R g[3][14];
+          V2<R> g[3][7];
 #pragma unroll
           for (int k = 0; k < 3; k++) {
             R ct[3], cb[3];
             cross_(C.rT, C.dT[k], ct);
             cross_(C.rB, C.dB[k], cb);
             R wk = dot_(C.wc, C.dT[k]);
-#pragma unroll
-            for (int i = 0; i < 3; i++) { g[k][i] = -C.dT[k][i]; g[k][3 + i] = -ct[i]; g[k][8 + i] = C.dB[k][i]; g[k][11 + i] = cb[i]; }
-            g[k][6] = C.sel == 1 ? -wk : (R)0;
-            g[k][7] = C.sel == 2 ? -wk : (R)0;
+            g[k][0] = v2_make(-C.dT[k][0], -C.dT[k][1]); g[k][1] = v2_make(-C.dT[k][2], -ct[0]); g[k][2] = v2_make(-ct[1], -ct[2]);
+            g[k][3] = v2_make(C.sel == 1 ? -wk : (R)0, C.sel == 2 ? -wk : (R)0);
+            g[k][4] = v2_make(C.dB[k][0], C.dB[k][1]); g[k][5] = v2_make(C.dB[k][2], cb[0]); g[k][6] = v2_make(cb[1], cb[2]);
           }
-          int mk = rows_into<0, 14>(H, rhs, g[0], g[1], g[2], C.mu, C.D, C.An, C.Bt1, C.Bt2, first && meta_h(C.meta) != 17, meta_new(C.meta), x, cst);
+          int mk = contact_into<0, 7>(H, rhs2, g[0], g[1], g[2], C.mu, C.D, C.An, C.Bt1, C.Bt2, first && meta_h(C.meta) != 17,
+                                      meta_new(C.meta), x2);
           st.setc(c, 13, (R)meta_make(C.sel, mk, mk));
         }
       }
-      cost_x = cst;
     }
 
     // x: in = warm start, out = minimiser; fcon: out = J^T f at the minimiser
@@ -913,15 +1000,17 @@ template <typename R, bool BLK> struct Sim {
       bool first = true;
       BRS_STAT(stats().solves[0]++; stats().last_iters[0] = 0);
       for (int it = 0; it < 16; it++) {
-        R H[NHH], rhs[NN], xn[NN], ft[NN], c0, ct;
+        V2<R> H[NH2], rhs2[NP];
+        R rhs[NN], xn[NN], ft[NN], ct;
         bool same;
         BRS_STAT(stats().iters[0]++; stats().last_iters[0]++);
-        assemble(P, st, F, x, a0, first, H, rhs, c0);
-        if (first) cost = c0;
+        assemble(P, st, F, x, a0, first, H, rhs2);
         first = false;
 #pragma unroll
+        for (int k = 0; k < NP; k++) { rhs[2 * k] = rhs2[k].x; if (2 * k + 1 < NN) rhs[2 * k + 1] = rhs2[k].y; }
+#pragma unroll
         for (int i = 0; i < NN; i++) xn[i] = 0;
-        chol_solve_block<R, 0, NN>(H, rhs, xn);
+        chol_solve_packed<R, NN>(H, rhs, xn);
         passA(P, st, F, xn, a0, ct, ft, same);
         bool full = true;
         // pure active-set iteration for the first sweeps (it terminates at once in ~97% of the substeps); if it has not

@@ -43,16 +43,12 @@ __global__ void __launch_bounds__(256) brs_step_kernel(const Params<float> P, co
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;  // no barriers anywhere: a partial last wave just masks lanes
   Store<float> st = lane_store<BLK>(lds);
-  EnvState<float, BLK> S;
-  load_state<float, BLK>(S, d, f, ii, (size_t)N, (size_t)i);
   Stream<float> rng;
-  rng.open(P.seed, P.gid_base + (int64_t)i, S.rng_ctr);
+  rng.open(P.seed, P.gid_base + (int64_t)i, 0u);
   const float a0 = actions[2 * (size_t)i], a1 = actions[2 * (size_t)i + 1];
   float o[6], to[6], rew;
   int te, tr;
-  Sim<float, BLK>::env_step(P, st, S, rng, a0, a1, o, to, rew, te, tr);
-  S.rng_ctr = rng.ctr;
-  store_state<float, BLK>(S, d, f, ii, (size_t)N, (size_t)i);
+  env_step_mem<float, BLK, float>(P, st, rng, d, f, ii, (size_t)N, (size_t)i, a0, a1, o, to, rew, te, tr);
 #pragma unroll
   for (int k = 0; k < 6; k++) obs[6 * (size_t)i + k] = o[k];
   if (terminal_obs) {

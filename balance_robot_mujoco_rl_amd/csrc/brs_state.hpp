@@ -28,8 +28,9 @@ template <bool BLK> struct Layout {
   static constexpr size_t bytes_per_env = (size_t)ND * 8 + (size_t)NF * 4 + (size_t)NI * 4;
 };
 
+// physics half of the state (what the 250-substep loop needs) ...
 template <typename R, bool BLK, typename FT>
-BRS_HD void load_state(EnvState<R, BLK>& S, const double* d, const FT* f, const int* ii, size_t N, size_t i) {
+BRS_HD void load_state_phys(EnvState<R, BLK>& S, const double* d, const FT* f, const int* ii, size_t N, size_t i) {
   using L = Layout<BLK>;
 #pragma unroll
   for (int k = 0; k < 3; k++) { S.p[k] = d[(L::D_P + k) * N + i]; S.xp[k] = d[(L::D_XP + k) * N + i]; }
@@ -42,8 +43,6 @@ BRS_HD void load_state(EnvState<R, BLK>& S, const double* d, const FT* f, const 
   S.ww[0] = (R)f[(L::F_WW + 0) * N + i]; S.ww[1] = (R)f[(L::F_WW + 1) * N + i];
 #pragma unroll
   for (int k = 0; k < L::NV; k++) S.a[k] = (R)f[(L::F_A + k) * N + i];
-  S.last_pitch = (R)f[L::F_LASTPITCH * N + i];
-  S.ep_return = (R)f[L::F_EPRET * N + i];
   if constexpr (BLK) {
 #pragma unroll
     for (int k = 0; k < 3; k++) {
@@ -53,14 +52,25 @@ BRS_HD void load_state(EnvState<R, BLK>& S, const double* d, const FT* f, const 
     }
 #pragma unroll
     for (int k = 0; k < 4; k++) S.bq[k] = d[(L::D_BQ + k) * N + i];
-    S.block_timer = d[L::D_TIMER * N + i];
-  } else
-    S.block_timer = -1.0;
-  S.elapsed = ii[L::I_ELAPSED * N + i];
+  }
   S.rng_ctr = (uint32_t)ii[L::I_RNG * N + i];
   S.side_front = ii[L::I_SIDE * N + i];
-  S.bad = ii[L::I_BAD * N + i];
   S.pnfr = 0; S.pnfb = 0; S.pnc = 0;
+}
+// ... and the env-level scalars, only needed before and after the loop
+template <typename R, bool BLK, typename FT>
+BRS_HD void load_state_env(EnvState<R, BLK>& S, const double* d, const FT* f, const int* ii, size_t N, size_t i) {
+  using L = Layout<BLK>;
+  S.last_pitch = (R)f[L::F_LASTPITCH * N + i];
+  S.ep_return = (R)f[L::F_EPRET * N + i];
+  if constexpr (BLK) S.block_timer = d[L::D_TIMER * N + i]; else S.block_timer = -1.0;
+  S.elapsed = ii[L::I_ELAPSED * N + i];
+  S.bad = ii[L::I_BAD * N + i];
+}
+template <typename R, bool BLK, typename FT>
+BRS_HD void load_state(EnvState<R, BLK>& S, const double* d, const FT* f, const int* ii, size_t N, size_t i) {
+  load_state_phys<R, BLK, FT>(S, d, f, ii, N, i);
+  load_state_env<R, BLK, FT>(S, d, f, ii, N, i);
 }
 
 template <typename R, bool BLK, typename FT>
@@ -94,6 +104,44 @@ BRS_HD void store_state(const EnvState<R, BLK>& S, double* d, FT* f, int* ii, si
   ii[L::I_RNG * N + i] = (int)S.rng_ctr;
   ii[L::I_SIDE * N + i] = S.side_front;
   ii[L::I_BAD * N + i] = S.bad;
+}
+
+// One full env step working from / to the SoA state in memory (the HIP step kernel's body; the host test build runs
+// the same function).  Register diet for the 250-substep loop: the accessor pose of the LAST forward pass is written
+// straight to its HBM slot when the last substep starts and read back afterwards, and the env-level scalars are only
+// loaded after the loop -- neither is live while the solver needs every VGPR.
+template <typename R, bool BLK, typename FT>
+BRS_HD void env_step_mem(const Params<R>& P, Store<R>& st, Stream<R>& rng, double* d, FT* f, int* ii, size_t N, size_t i,
+                         float a0, float a1, float* obs, float* terminal_obs, float& reward, int& terminated, int& truncated) {
+  using L = Layout<BLK>;
+  using SimT = Sim<R, BLK>;
+  EnvState<R, BLK> S;
+  load_state_phys<R, BLK, FT>(S, d, f, ii, N, i);
+  rng.ctr = S.rng_ctr;
+  R ctrlL, ctrlR;
+  R rew = SimT::env_pre(P, S, rng, a0, a1, ctrlL, ctrlR);
+  for (int k = 0; k < P.nsub; k++) {
+    if (k == P.nsub - 1) {  // wave-uniform branch
+#pragma unroll
+      for (int j = 0; j < 4; j++) d[(L::D_XQ + j) * N + i] = S.q[j];
+#pragma unroll
+      for (int j = 0; j < 3; j++) d[(L::D_XP + j) * N + i] = S.p[j];
+    }
+    SimT::substep(P, st, S, ctrlL, ctrlR);
+  }
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" ::: "memory");  // re-read the pose from memory: do not keep it in registers across the loop
+#endif
+  if (P.nsub > 0) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) S.xq[j] = d[(L::D_XQ + j) * N + i];
+#pragma unroll
+    for (int j = 0; j < 3; j++) S.xp[j] = d[(L::D_XP + j) * N + i];
+  }
+  load_state_env<R, BLK, FT>(S, d, f, ii, N, i);
+  SimT::env_post(P, S, rng, rew, obs, terminal_obs, reward, terminated, truncated);
+  S.rng_ctr = rng.ctr;
+  store_state<R, BLK, FT>(S, d, f, ii, N, i);
 }
 
 // ---------------------------------------------------------------------------------- host conversions (fp64)

@@ -91,18 +91,16 @@ template <typename R, bool BLK> struct HostSim : IHost {
   void step(const float* act, float* obs, float* rew, uint8_t* term, uint8_t* trunc, float* tobs) override {
     R buf[LDS_WORDS_ENV03];
     for (size_t i = 0; i < N; i++) {
-      ES S;
-      load_state<R, BLK>(S, d.data(), f.data(), ii.data(), N, i);
       Stream<R> rng;
-      open_stream(rng, S, i);
+      rng.open(P.seed, P.gid_base + (int64_t)i, 0u);
+      if (!scripts[i].empty()) { rng.script = scripts[i].data(); rng.script_n = (int)scripts[i].size(); rng.script_pos = spos[i]; }
       Store<R> st{buf, 1};
       int te, tr;
       float tob[6];
-      Sim<R, BLK>::env_step(P, st, S, rng, act[2 * i], act[2 * i + 1], obs + 6 * i, tob, rew[i], te, tr);
+      env_step_mem<R, BLK, R>(P, st, rng, d.data(), f.data(), ii.data(), N, i, act[2 * i], act[2 * i + 1], obs + 6 * i, tob, rew[i], te, tr);
+      spos[i] = rng.script_pos;
       term[i] = (uint8_t)te; trunc[i] = (uint8_t)tr;
       if (tobs) memcpy(tobs + 6 * i, tob, sizeof tob);
-      close_stream(rng, S, i);
-      store_state<R, BLK>(S, d.data(), f.data(), ii.data(), N, i);
     }
   }
   // physics replaced by a scripted post-step state, exactly like tools/gen_golden.py's stubbed mj_step
