@@ -994,45 +994,54 @@ template <typename R, bool BLK> struct Sim {
       }
     }
 
-    // x: in = warm start, out = minimiser; fcon: out = J^T f at the minimiser
-    static BRS_HD void solve(const Params<R>& P, Store<R>& st, const Frame& F, R* x, const R* a0, R* fcon) {
-      R cost = 0;
-      bool first = true;
-      BRS_STAT(stats().solves[0]++; stats().last_iters[0] = 0);
-      for (int it = 0; it < 16; it++) {
-        V2<R> H[NH2], rhs2[NP];
-        R rhs[NN], xn[NN], ft[NN], ct;
-        bool same;
-        BRS_STAT(stats().iters[0]++; stats().last_iters[0]++);
-        assemble(P, st, F, x, a0, first, H, rhs2);
-        first = false;
+    // ONE Newton iteration at x (in/out); fcon out = J^T f at the new x.  Returns true when the new point is the
+    // minimiser (a full step that reproduced its own active set) or the iteration cap is reached.
+    // State carried by the caller across iterations of one substep: first (true on entry), it (0), cost.
+    static BRS_HD bool iterate(const Params<R>& P, Store<R>& st, const Frame& F, R* x, const R* a0, R* fcon, bool& first, int& it,
+                               R& cost) {
+      V2<R> H[NH2], rhs2[NP];
+      R rhs[NN], xn[NN], ft[NN], ct;
+      bool same;
+      BRS_STAT(stats().iters[0]++; stats().last_iters[0]++);
+      assemble(P, st, F, x, a0, first, H, rhs2);
+      first = false;
 #pragma unroll
-        for (int k = 0; k < NP; k++) { rhs[2 * k] = rhs2[k].x; if (2 * k + 1 < NN) rhs[2 * k + 1] = rhs2[k].y; }
+      for (int k = 0; k < NP; k++) { rhs[2 * k] = rhs2[k].x; if (2 * k + 1 < NN) rhs[2 * k + 1] = rhs2[k].y; }
 #pragma unroll
-        for (int i = 0; i < NN; i++) xn[i] = 0;
-        chol_solve_packed<R, NN>(H, rhs, xn);
+      for (int i = 0; i < NN; i++) xn[i] = 0;
+      chol_solve_packed<R, NN>(H, rhs, xn);
+      passA(P, st, F, xn, a0, ct, ft, same);
+      bool full = true;
+      // pure active-set iteration for the first sweeps (it terminates at once in ~97% of the substeps); if it has not
+      // settled by then, fall back to cost-monotone damping, which cannot cycle
+      for (int bt = 0; it >= BRS_UNDAMPED_ITERS && bt < 6 && ct > cost + (R)1e-5 * abs_(cost) + (R)1e-12; bt++) {
+        full = false;
+        BRS_STAT(stats().backtracks[0]++);
+#pragma unroll
+        for (int i = 0; i < NN; i++) xn[i] = x[i] + (R)0.5 * (xn[i] - x[i]);
         passA(P, st, F, xn, a0, ct, ft, same);
-        bool full = true;
-        // pure active-set iteration for the first sweeps (it terminates at once in ~97% of the substeps); if it has not
-        // settled by then, fall back to cost-monotone damping, which cannot cycle
-        for (int bt = 0; it >= BRS_UNDAMPED_ITERS && bt < 6 && ct > cost + (R)1e-5 * abs_(cost) + (R)1e-12; bt++) {
-          full = false;
-          BRS_STAT(stats().backtracks[0]++);
-#pragma unroll
-          for (int i = 0; i < NN; i++) xn[i] = x[i] + (R)0.5 * (xn[i] - x[i]);
-          passA(P, st, F, xn, a0, ct, ft, same);
-        }
-        cost = ct;
-#pragma unroll
-        for (int i = 0; i < NN; i++) { x[i] = xn[i]; fcon[i] = ft[i]; }
-        if (same && full) break;
       }
+      cost = ct;
+#pragma unroll
+      for (int i = 0; i < NN; i++) { x[i] = xn[i]; fcon[i] = ft[i]; }
+      it++;
+      return (same && full) || it >= 16;
     }
   };
 
-  // ---- the substep
-  static BRS_HD void substep(const Params<R>& P, Store<R>& st, ES& S, R ctrlL, R ctrlR) {
+  // ---- the substep, in three pieces so that the caller can FLATTEN the substep loop and the Newton loop into one
+  // per-lane state machine: sub_begin (kinematics, smooth forces, collision) -> sub_iter until converged -> sub_end
+  // (implicitfast + advance).  In a wave, a lane that converged starts its next substep while its neighbours are
+  // still iterating: the wave needs ~nsub * mean(iterations) trips instead of nsub * max-over-lanes(iterations).
+  struct SubCtx {
     Frame F;
+    R f[8], fcon[NV], cost;
+    bool clL, clR, conv, first;
+    int it;
+  };
+  static BRS_HD void sub_begin(const Params<R>& P, Store<R>& st, ES& S, R ctrlL, R ctrlR, SubCtx& C) {
+    Frame& F = C.F;
+    R* f = C.f;
     // kinematics
     R qf[4] = {(R)S.q[0], (R)S.q[1], (R)S.q[2], (R)S.q[3]};
     quat2mat_(qf, F.RT);
@@ -1044,7 +1053,6 @@ template <typename R, bool BLK> struct Sim {
     // smooth forces in body coordinates
     R wx = S.w[0], wy = S.w[1], wz = S.w[2];
     R gb[3] = {-P.g * F.nT[0], -P.g * F.nT[1], -P.g * F.nT[2]};
-    R f[8];
     f[0] = -P.mcz * wx * wz + P.m * gb[0];
     f[1] = -P.mcz * wy * wz + P.m * gb[1];
     f[2] = P.mcz * (wx * wx + wy * wy) + P.m * gb[2];
@@ -1055,7 +1063,8 @@ template <typename R, bool BLK> struct Sim {
     // velocity servos (envs/robot-02.xml:22-25): ctrl clamp, force clamp; derivative dropped when clamped
     R uL = min_(max_(ctrlL, -P.ctrlrange), P.ctrlrange), uR = min_(max_(ctrlR, -P.ctrlrange), P.ctrlrange);
     R fL = P.kv * (uL - S.ww[0]), fR = P.kv * (uR - S.ww[1]);
-    bool clL = fL >= P.forcerange || fL <= -P.forcerange, clR = fR >= P.forcerange || fR <= -P.forcerange;
+    C.clL = fL >= P.forcerange || fL <= -P.forcerange;
+    C.clR = fR >= P.forcerange || fR <= -P.forcerange;
     fL = min_(max_(fL, -P.forcerange), P.forcerange);
     fR = min_(max_(fR, -P.forcerange), P.forcerange);
     f[6] = fL - P.damping * S.ww[0];
@@ -1069,7 +1078,6 @@ template <typename R, bool BLK> struct Sim {
     collide_torso(P, st, F, u, S.w, S.ww, zT);
     collide_wheel(P, st, F, u, S.w, S.ww, zT, 1, true);
     collide_wheel(P, st, F, u, S.w, S.ww, zT, 2, true);
-    R fblk[6];
     if constexpr (BLK) {
       R qb[4] = {(R)S.bq[0], (R)S.bq[1], (R)S.bq[2], (R)S.bq[3]};
       quat2mat_(qb, F.RB);
@@ -1081,8 +1089,6 @@ template <typename R, bool BLK> struct Sim {
 #pragma unroll
       for (int i = 0; i < 3; i++) {
         F.dTB[i] = (R)(S.p[i] - S.bp[i]);
-        fblk[i] = -P.mB * P.g * F.nB[i];
-        fblk[3 + i] = 0;  // isotropic inertia: no gyroscopic torque
         F.a0[8 + i] = -P.g * F.nB[i];
         F.a0[11 + i] = 0;
       }
@@ -1092,13 +1098,22 @@ template <typename R, bool BLK> struct Sim {
 #endif
     }
     S.pnfr = F.nfr; S.pnfb = F.nfb; S.pnc = F.nc;
-    // constraint solve
-    R fcon[NV];
-    if (F.nfr + F.nfb + F.nc == 0) {
+    C.first = true; C.it = 0; C.cost = 0;
+    C.conv = F.nfr + F.nfb + F.nc == 0;
+    if (C.conv) {  // no contacts: the unconstrained acceleration is the answer
 #pragma unroll
-      for (int i = 0; i < NV; i++) { S.a[i] = F.a0[i]; fcon[i] = 0; }
-    } else
-      Solver::solve(P, st, F, S.a, F.a0, fcon);
+      for (int i = 0; i < NV; i++) { S.a[i] = F.a0[i]; C.fcon[i] = 0; }
+    }
+    BRS_STAT(if (!C.conv) { stats().solves[0]++; stats().last_iters[0] = 0; });
+  }
+  static BRS_HD void sub_iter(const Params<R>& P, Store<R>& st, ES& S, SubCtx& C) {
+    C.conv = Solver::iterate(P, st, C.F, S.a, C.F.a0, C.fcon, C.first, C.it, C.cost);
+  }
+  static BRS_HD void sub_end(const Params<R>& P, ES& S, SubCtx& C) {
+    const Frame& F = C.F;
+    const R* f = C.f;
+    const R* fcon = C.fcon;
+    const bool clL = C.clL, clR = C.clR;
     // implicitfast: (M + h*diag(damping + kv[unclamped])) acc = smooth + constraint
     R rhs[8], acc[8];
 #pragma unroll
@@ -1118,15 +1133,23 @@ template <typename R, bool BLK> struct Sim {
     S.th[0] += P.h_d * (double)S.ww[0];
     S.th[1] += P.h_d * (double)S.ww[1];
     if constexpr (BLK) {
-      R ab[3], al[3] = {(fblk[0] + fcon[8]) * P.inv_mB, (fblk[1] + fcon[9]) * P.inv_mB, (fblk[2] + fcon[10]) * P.inv_mB};
+      // block smooth force: gravity only (isotropic inertia: no gyroscopic torque)
+      R ab[3], al[3] = {fcon[8] * P.inv_mB - P.g * F.nB[0], fcon[9] * P.inv_mB - P.g * F.nB[1], fcon[10] * P.inv_mB - P.g * F.nB[2]};
       mul_(F.RB, al, ab);
 #pragma unroll
-      for (int i = 0; i < 3; i++) { S.bv[i] += P.h * ab[i]; S.bw[i] += P.h * (fblk[3 + i] + fcon[11 + i]) * P.inv_IB; }
+      for (int i = 0; i < 3; i++) { S.bv[i] += P.h * ab[i]; S.bw[i] += P.h * fcon[11 + i] * P.inv_IB; }
 #pragma unroll
       for (int i = 0; i < 3; i++) S.bp[i] += P.h_d * (double)S.bv[i];
       quat_advance(S.bq, (double)S.bw[0], (double)S.bw[1], (double)S.bw[2], P.h_d);
     }
     S.time += P.h_d;
+  }
+  // un-flattened form (one lane at a time: host tests, single substeps)
+  static BRS_HD void substep(const Params<R>& P, Store<R>& st, ES& S, R ctrlL, R ctrlR) {
+    SubCtx C;
+    sub_begin(P, st, S, ctrlL, ctrlR, C);
+    while (!C.conv) sub_iter(P, st, S, C);
+    sub_end(P, S, C);
   }
 
   // =================================================================================== env logic

@@ -87,17 +87,7 @@ __global__ void __launch_bounds__(256) brs_physics_kernel(const Params<float> P,
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   Store<float> st = lane_store<BLK>(lds);
-  EnvState<float, BLK> S;
-  load_state<float, BLK>(S, d, f, ii, (size_t)N, (size_t)i);
-  const float cl = ctrl[2 * (size_t)i], cr = ctrl[2 * (size_t)i + 1];
-  for (int k = 0; k < nsub; k++) {
-#pragma unroll
-    for (int j = 0; j < 4; j++) S.xq[j] = S.q[j];
-#pragma unroll
-    for (int j = 0; j < 3; j++) S.xp[j] = S.p[j];
-    Sim<float, BLK>::substep(P, st, S, cl, cr);
-  }
-  store_state<float, BLK>(S, d, f, ii, (size_t)N, (size_t)i);
+  physics_mem<float, BLK, float>(P, st, d, f, ii, (size_t)N, (size_t)i, ctrl[2 * (size_t)i], ctrl[2 * (size_t)i + 1], nsub);
 }
 
 thread_local std::string g_create_error;

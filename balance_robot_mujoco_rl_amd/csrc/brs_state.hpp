@@ -120,14 +120,28 @@ BRS_HD void env_step_mem(const Params<R>& P, Store<R>& st, Stream<R>& rng, doubl
   rng.ctr = S.rng_ctr;
   R ctrlL, ctrlR;
   R rew = SimT::env_pre(P, S, rng, a0, a1, ctrlL, ctrlR);
-  for (int k = 0; k < P.nsub; k++) {
-    if (k == P.nsub - 1) {  // wave-uniform branch
+  {  // flattened substep x Newton loop: one trip = [start a substep] + [one Newton iteration] + [finish the substep]
+    typename SimT::SubCtx C;
+    int k = 0;
+    bool fresh = true;
+    while (k < P.nsub) {
+      if (fresh) {
+        if (k == P.nsub - 1) {
 #pragma unroll
-      for (int j = 0; j < 4; j++) d[(L::D_XQ + j) * N + i] = S.q[j];
+          for (int j = 0; j < 4; j++) d[(L::D_XQ + j) * N + i] = S.q[j];
 #pragma unroll
-      for (int j = 0; j < 3; j++) d[(L::D_XP + j) * N + i] = S.p[j];
+          for (int j = 0; j < 3; j++) d[(L::D_XP + j) * N + i] = S.p[j];
+        }
+        SimT::sub_begin(P, st, S, ctrlL, ctrlR, C);
+        fresh = false;
+      }
+      if (!C.conv) SimT::sub_iter(P, st, S, C);
+      if (C.conv) {
+        SimT::sub_end(P, S, C);
+        k++;
+        fresh = true;
+      }
     }
-    SimT::substep(P, st, S, ctrlL, ctrlR);
   }
 #if defined(__HIP_DEVICE_COMPILE__)
   asm volatile("" ::: "memory");  // re-read the pose from memory: do not keep it in registers across the loop
@@ -141,6 +155,34 @@ BRS_HD void env_step_mem(const Params<R>& P, Store<R>& st, Stream<R>& rng, doubl
   load_state_env<R, BLK, FT>(S, d, f, ii, N, i);
   SimT::env_post(P, S, rng, rew, obs, terminal_obs, reward, terminated, truncated);
   S.rng_ctr = rng.ctr;
+  store_state<R, BLK, FT>(S, d, f, ii, N, i);
+}
+
+// physics only (parity tests): nsub substeps with ctrl held, same flattened loop
+template <typename R, bool BLK, typename FT>
+BRS_HD void physics_mem(const Params<R>& P, Store<R>& st, double* d, FT* f, int* ii, size_t N, size_t i, R ctrlL, R ctrlR, int nsub) {
+  using SimT = Sim<R, BLK>;
+  EnvState<R, BLK> S;
+  load_state<R, BLK, FT>(S, d, f, ii, N, i);
+  typename SimT::SubCtx C;
+  int k = 0;
+  bool fresh = true;
+  while (k < nsub) {
+    if (fresh) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) S.xq[j] = S.q[j];
+#pragma unroll
+      for (int j = 0; j < 3; j++) S.xp[j] = S.p[j];
+      SimT::sub_begin(P, st, S, ctrlL, ctrlR, C);
+      fresh = false;
+    }
+    if (!C.conv) SimT::sub_iter(P, st, S, C);
+    if (C.conv) {
+      SimT::sub_end(P, S, C);
+      k++;
+      fresh = true;
+    }
+  }
   store_state<R, BLK, FT>(S, d, f, ii, N, i);
 }
 

@@ -65,15 +65,8 @@ template <typename R, bool BLK> struct HostSim : IHost {
   void physics(const double* ctrl, int nsub) override {
     R buf[LDS_WORDS_ENV03];
     for (size_t i = 0; i < N; i++) {
-      ES S;
-      load_state<R, BLK>(S, d.data(), f.data(), ii.data(), N, i);
       Store<R> st{buf, 1};
-      for (int k = 0; k < nsub; k++) {
-        for (int j = 0; j < 4; j++) S.xq[j] = S.q[j];
-        for (int j = 0; j < 3; j++) S.xp[j] = S.p[j];
-        Sim<R, BLK>::substep(P, st, S, (R)ctrl[2 * i], (R)ctrl[2 * i + 1]);
-      }
-      store_state<R, BLK>(S, d.data(), f.data(), ii.data(), N, i);
+      physics_mem<R, BLK, R>(P, st, d.data(), f.data(), ii.data(), N, i, (R)ctrl[2 * i], (R)ctrl[2 * i + 1], nsub);
     }
   }
   void reset(const uint8_t* mask, float* obs) override {
