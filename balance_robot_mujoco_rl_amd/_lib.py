@@ -37,7 +37,10 @@ def build(force=False, verbose=False):
     stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if not (force or stale):
         return LIB_PATH
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB_PATH, SRC]
+    # -ffast-math on the DEVICE side only (the host-side state conversion keeps IEEE semantics): no IEEE division/sqrt expansions and free reassociation inside the fp32 force path
+    # (parity budget is 1e-4, rounding noise 1e-7); NaN detection in the kernel is done on the bit pattern.
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-Xarch_device", "-ffast-math",
+           "-Xarch_device", "-fgpu-flush-denormals-to-zero", "-fPIC", "-shared", "-o", LIB_PATH, SRC]
     if verbose:
         cmd.append("-Rpass-analysis=kernel-resource-usage")
     subprocess.check_call(cmd)

@@ -24,6 +24,11 @@
 #define BRS_HD inline
 #endif
 
+#if defined(BRS_MARKERS) && defined(__HIP_DEVICE_COMPILE__)
+#define BRS_MARK(name) asm volatile("; BRS_MARK " name)
+#else
+#define BRS_MARK(name) do { } while (0)
+#endif
 #ifndef BRS_MASK_HINT
 #define BRS_MASK_HINT 1
 #endif
@@ -48,11 +53,17 @@ inline Stats& stats() { static thread_local Stats s{}; return s; }
 #endif
 
 // ------------------------------------------------------------------------------------ math wrappers
-BRS_HD float sqrt_(float x) { return sqrtf(x); }
+BRS_HD float sqrt_(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_sqrtf(x);  // v_sqrt_f32, 1 ulp
+#else
+  return sqrtf(x);
+#endif
+}
 BRS_HD double sqrt_(double x) { return sqrt(x); }
 BRS_HD float rsqrt_(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  return rsqrtf(x);
+  return __builtin_amdgcn_rsqf(x);  // v_rsq_f32, 1 ulp
 #else
   return 1.0f / sqrtf(x);
 #endif
@@ -60,7 +71,7 @@ BRS_HD float rsqrt_(float x) {
 BRS_HD double rsqrt_(double x) { return 1.0 / sqrt(x); }
 BRS_HD float rcp_(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  return __frcp_rn(x);
+  return __builtin_amdgcn_rcpf(x);  // v_rcp_f32, 1 ulp (an IEEE division costs ~10 instructions)
 #else
   return 1.0f / x;
 #endif
@@ -72,6 +83,8 @@ BRS_HD float atan2_(float y, float x) { return atan2f(y, x); }
 BRS_HD double atan2_(double y, double x) { return atan2(y, x); }
 BRS_HD void sincos_(float x, float* s, float* c) { *s = sinf(x); *c = cosf(x); }
 BRS_HD void sincos_(double x, double* s, double* c) { *s = sin(x); *c = cos(x); }
+BRS_HD bool isbad_(float x) { union { float f; uint32_t u; } c; c.f = x; return (c.u & 0x7fffffffu) >= 0x7f800000u; }  // NaN or Inf
+BRS_HD bool isbad_(double x) { union { double f; uint64_t u; } c; c.f = x; return (c.u & 0x7fffffffffffffffull) >= 0x7ff0000000000000ull; }
 template <typename R> BRS_HD R max_(R a, R b) { return a > b ? a : b; }
 template <typename R> BRS_HD R min_(R a, R b) { return a < b ? a : b; }
 
@@ -941,6 +954,7 @@ template <typename R, bool BLK> struct Sim {
       V2<R> x2[NP];
 #pragma unroll
       for (int k = 0; k < NP; k++) { x2[k] = v2_make(x[2 * k], x[2 * k + 1]); rhs2[k] = v2_make(rhs[2 * k], rhs[2 * k + 1]); }
+      BRS_MARK("asm_robot_loop");
       for (int c = 0; c < F.nfr; c++) {
         int s = SLOT_ROBOT + c;
         R r[3] = {st.get(s, 0), st.get(s, 1), st.get(s, 2)};
@@ -1003,14 +1017,18 @@ template <typename R, bool BLK> struct Sim {
       R rhs[NN], xn[NN], ft[NN], ct;
       bool same;
       BRS_STAT(stats().iters[0]++; stats().last_iters[0]++);
+      BRS_MARK("iter_assemble");
       assemble(P, st, F, x, a0, first, H, rhs2);
       first = false;
+      BRS_MARK("iter_chol");
 #pragma unroll
       for (int k = 0; k < NP; k++) { rhs[2 * k] = rhs2[k].x; if (2 * k + 1 < NN) rhs[2 * k + 1] = rhs2[k].y; }
 #pragma unroll
       for (int i = 0; i < NN; i++) xn[i] = 0;
       chol_solve_packed<R, NN>(H, rhs, xn);
+      BRS_MARK("iter_passA");
       passA(P, st, F, xn, a0, ct, ft, same);
+      BRS_MARK("iter_tail");
       bool full = true;
       // pure active-set iteration for the first sweeps (it terminates at once in ~97% of the substeps); if it has not
       // settled by then, fall back to cost-monotone damping, which cannot cycle
@@ -1042,6 +1060,7 @@ template <typename R, bool BLK> struct Sim {
   static BRS_HD void sub_begin(const Params<R>& P, Store<R>& st, ES& S, R ctrlL, R ctrlR, SubCtx& C) {
     Frame& F = C.F;
     R* f = C.f;
+    BRS_MARK("begin_kin");
     // kinematics
     R qf[4] = {(R)S.q[0], (R)S.q[1], (R)S.q[2], (R)S.q[3]};
     quat2mat_(qf, F.RT);
@@ -1070,6 +1089,7 @@ template <typename R, bool BLK> struct Sim {
     f[6] = fL - P.damping * S.ww[0];
     f[7] = fR - P.damping * S.ww[1];
     msolve0_(P, f, F.a0);
+    BRS_MARK("begin_collide_robot");
     // collision: robot <-> floor.  Slot priority: wheel main points, torso corners, wheel triangle points
     F.nfr = 0; F.nfb = 0; F.nc = 0;
     F.pnfr = S.pnfr; F.pnfb = S.pnfb; F.pnc = S.pnc;
@@ -1092,12 +1112,15 @@ template <typename R, bool BLK> struct Sim {
         F.a0[8 + i] = -P.g * F.nB[i];
         F.a0[11 + i] = 0;
       }
+      BRS_MARK("begin_collide_blockfloor");
       collide_block_floor(P, st, F, uB, S.bw, zB);
+      BRS_MARK("begin_collide_coupled");
 #ifndef BRS_NO_COUPLED
       collide_coupled(P, st, F, S);
 #endif
     }
     S.pnfr = F.nfr; S.pnfb = F.nfb; S.pnc = F.nc;
+    BRS_MARK("begin_tail");
     C.first = true; C.it = 0; C.cost = 0;
     C.conv = F.nfr + F.nfb + F.nc == 0;
     if (C.conv) {  // no contacts: the unconstrained acceleration is the answer
@@ -1110,6 +1133,7 @@ template <typename R, bool BLK> struct Sim {
     C.conv = Solver::iterate(P, st, C.F, S.a, C.F.a0, C.fcon, C.first, C.it, C.cost);
   }
   static BRS_HD void sub_end(const Params<R>& P, ES& S, SubCtx& C) {
+    BRS_MARK("end_integrate");
     const Frame& F = C.F;
     const R* f = C.f;
     const R* fcon = C.fcon;
@@ -1143,6 +1167,7 @@ template <typename R, bool BLK> struct Sim {
       quat_advance(S.bq, (double)S.bw[0], (double)S.bw[1], (double)S.bw[2], P.h_d);
     }
     S.time += P.h_d;
+    BRS_MARK("end_done");
   }
   // un-flattened form (one lane at a time: host tests, single substeps)
   static BRS_HD void substep(const Params<R>& P, Store<R>& st, ES& S, R ctrlL, R ctrlR) {
@@ -1261,9 +1286,9 @@ template <typename R, bool BLK> struct Sim {
   static BRS_HD void env_post(const Params<R>& P, ES& S, Stream<R>& rng, R rew, float* obs, float* terminal_obs, float& reward,
                               int& terminated, int& truncated) {
     // mj_check*: NaN / runaway -> reset the simulation (counted)
-    bool bad = !(S.p[0] == S.p[0]) || !(S.q[0] == S.q[0]) || !(S.v[0] == S.v[0]) || abs_(S.v[0]) > (R)1e10 ||
-               abs_(S.v[2]) > (R)1e10 || !(S.ww[0] == S.ww[0]);
-    if constexpr (BLK) bad = bad || !(S.bp[0] == S.bp[0]) || !(S.bv[0] == S.bv[0]);
+    bool bad = isbad_(S.p[0]) || isbad_(S.p[2]) || isbad_(S.q[0]) || isbad_(S.v[0]) || isbad_(S.v[2]) || isbad_(S.w[0]) ||
+               isbad_(S.ww[0]) || isbad_(S.ww[1]) || abs_(S.v[0]) > (R)1e10 || abs_(S.v[2]) > (R)1e10;
+    if constexpr (BLK) bad = bad || isbad_(S.bp[0]) || isbad_(S.bp[2]) || isbad_(S.bq[0]) || isbad_(S.bv[0]) || isbad_(S.bw[0]);
     if (bad) {
       float tmp[6];
       S.bad++;

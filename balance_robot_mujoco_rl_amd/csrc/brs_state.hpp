@@ -189,6 +189,8 @@ BRS_HD void physics_mem(const Params<R>& P, Store<R>& st, double* d, FT* f, int*
 // ---------------------------------------------------------------------------------- host conversions (fp64)
 namespace hostconv {
 
+// NaN test on the bit pattern (this header may be compiled with -ffast-math, which folds x != x)
+inline bool isnan_bits(double x) { union { double f; uint64_t u; } c; c.f = x; return (c.u & 0x7fffffffffffffffull) > 0x7ff0000000000000ull; }
 inline void quat_norm(double* q) {
   double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
   if (n < 1e-15) { q[0] = 1; q[1] = q[2] = q[3] = 0; return; }
@@ -311,7 +313,7 @@ template <bool BLK, typename FT> inline void get_aux(const double* d, const FT* 
     double* a = aux + 10 * i;
     a[0] = f[L::F_LASTPITCH * N + i];
     double t = BLK ? d[L::D_TIMER * N + i] : -1.0;
-    a[1] = t < 0 ? std::nan("") : t;
+    { union { double f; uint64_t u; } qn; qn.u = 0x7ff8000000000000ull; a[1] = t < 0 ? qn.f : t; }
     a[2] = ii[L::I_ELAPSED * N + i]; a[3] = (uint32_t)ii[L::I_RNG * N + i]; a[4] = ii[L::I_SIDE * N + i];
     double xq[4];
     for (int k = 0; k < 4; k++) xq[k] = d[(L::D_XQ + k) * N + i];
@@ -325,7 +327,7 @@ template <bool BLK, typename FT> inline void set_aux(double* d, FT* f, int* ii, 
   for (size_t i = 0; i < N; i++) {
     const double* a = aux + 10 * i;
     f[L::F_LASTPITCH * N + i] = (FT)a[0];
-    if (BLK) d[L::D_TIMER * N + i] = (a[1] != a[1]) ? -1.0 : a[1];
+    if (BLK) d[L::D_TIMER * N + i] = isnan_bits(a[1]) ? -1.0 : a[1];
     ii[L::I_ELAPSED * N + i] = (int)a[2]; ii[L::I_RNG * N + i] = (int)(uint32_t)a[3]; ii[L::I_SIDE * N + i] = a[4] != 0;
     f[L::F_EPRET * N + i] = (FT)a[6];
   }
