@@ -41,6 +41,7 @@ def build(force=False, verbose=False):
     # (parity budget is 1e-4, rounding noise 1e-7); NaN detection in the kernel is done on the bit pattern.
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-Xarch_device", "-ffast-math",
            "-Xarch_device", "-fgpu-flush-denormals-to-zero", "-fPIC", "-shared", "-o", LIB_PATH, SRC]
+    cmd += os.environ.get("BRS_EXTRA_HIPCC_FLAGS", "").split()  # ablation builds (e.g. -DBRS_NO_COUPLED); not for production
     if verbose:
         cmd.append("-Rpass-analysis=kernel-resource-usage")
     subprocess.check_call(cmd)

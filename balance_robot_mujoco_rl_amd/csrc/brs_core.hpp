@@ -809,9 +809,9 @@ template <typename R, bool BLK> struct Sim {
 
     // pass A: cost, constraint force J^T f and active-row masks at x; same = every mask equals the one H was built with
     static BRS_HD void passA(const Params<R>& P, Store<R>& st, const Frame& F, const R* x, const R* a0, R& cost, R* fcon,
-                             bool& same) {
-      R Md[NN], cst, l[4];
-      gauss(P, x, a0, Md, cst);
+                             bool& same, bool want_cost) {
+      R Md[NN], cst = 0, l[4];
+      if (want_cost) gauss(P, x, a0, Md, cst);  // the cost only steers the damped fallback (iterations >= BRS_UNDAMPED_ITERS)
 #pragma unroll
       for (int i = 0; i < NN; i++) fcon[i] = 0;
       bool sm = true;
@@ -1027,7 +1027,8 @@ template <typename R, bool BLK> struct Sim {
       for (int i = 0; i < NN; i++) xn[i] = 0;
       chol_solve_packed<R, NN>(H, rhs, xn);
       BRS_MARK("iter_passA");
-      passA(P, st, F, xn, a0, ct, ft, same);
+      const bool damped = it + 1 >= BRS_UNDAMPED_ITERS;  // the next iteration may need this point's cost
+      passA(P, st, F, xn, a0, ct, ft, same, damped);
       BRS_MARK("iter_tail");
       bool full = true;
       // pure active-set iteration for the first sweeps (it terminates at once in ~97% of the substeps); if it has not
@@ -1037,7 +1038,7 @@ template <typename R, bool BLK> struct Sim {
         BRS_STAT(stats().backtracks[0]++);
 #pragma unroll
         for (int i = 0; i < NN; i++) xn[i] = x[i] + (R)0.5 * (xn[i] - x[i]);
-        passA(P, st, F, xn, a0, ct, ft, same);
+        passA(P, st, F, xn, a0, ct, ft, same, true);
       }
       cost = ct;
 #pragma unroll
@@ -1113,7 +1114,9 @@ template <typename R, bool BLK> struct Sim {
         F.a0[11 + i] = 0;
       }
       BRS_MARK("begin_collide_blockfloor");
+#ifndef BRS_NO_BLOCKFLOOR
       collide_block_floor(P, st, F, uB, S.bw, zB);
+#endif
       BRS_MARK("begin_collide_coupled");
 #ifndef BRS_NO_COUPLED
       collide_coupled(P, st, F, S);
