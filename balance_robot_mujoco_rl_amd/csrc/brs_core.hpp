@@ -29,6 +29,29 @@
 #else
 #define BRS_MARK(name) do { } while (0)
 #endif
+// diagnostic build only (-DBRS_TIMING): per-phase wave cycles.  Stamps are fenced with sched_barrier so the compiler
+// cannot move work across them; lane 0 of the wave adds the interval to an LDS slot, flushed to brs_dbg at kernel end.
+#if defined(BRS_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+extern __device__ unsigned long long brs_dbg[16];
+__device__ __forceinline__ unsigned long long brs_stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+extern __shared__ float brs_lds_dyn[];
+__device__ __forceinline__ unsigned long long* brs_tim_slots() {  // 16 x u64 per wave, placed after the contact columns
+  return (unsigned long long*)(brs_lds_dyn + blockDim.x * (unsigned)BRS_TIMING_LANE_WORDS) + (threadIdx.x >> 6) * 16;
+}
+#define BRS_TIC(id) unsigned long long _brs_t##id = brs_stamp()
+#define BRS_PIN(x) asm volatile("" : "+v"(x))
+#define BRS_TOC(id) do { unsigned long long _d = brs_stamp() - _brs_t##id; if ((threadIdx.x & 63) == 0) brs_tim_slots()[id] += _d; } while (0)
+#else
+#define BRS_TIC(id) do { } while (0)
+#define BRS_TOC(id) do { } while (0)
+#define BRS_PIN(x) do { } while (0)
+#endif
 #ifndef BRS_MASK_HINT
 #define BRS_MASK_HINT 1
 #endif
@@ -190,6 +213,7 @@ BRS_HD int meta_sel(int m) { return m & 3; }
 BRS_HD int meta_new(int m) { return (m >> 2) & 15; }
 BRS_HD int meta_h(int m) { return (m >> 6) & 31; }
 BRS_HD int meta_make(int sel, int mnew, int mh) { return sel | (mnew << 2) | (mh << 6); }
+BRS_HD constexpr int META_SHARE = 2048;  // coupled contacts: same normal (same contact frame) as the previous slot
 // a slot that held a contact of the same body in the previous substep keeps that contact's final active rows as the
 // first guess of this substep's active set (maskH = 17: guess present, H not built yet; 16: no guess)
 template <typename R> BRS_HD int hint_meta(R oldword, int sel, bool existed) {
@@ -534,16 +558,13 @@ template <typename R, bool BLK> struct Sim {
     fw[3] *= il; fw[4] *= il; fw[5] *= il;
     cross_(fw, fw + 3, fw + 6);
   }
-  // coupled record (14 words): rT(3) torso frame, rB(3) block frame, nW(3) world normal robot->block, An, Bt1, Bt2, D, meta
-  static BRS_HD void add_coupled(const Params<R>& P, Store<R>& st, Frame& F, const ES& S, const R* rT, const R* nTf, R dist,
-                                 int sel) {
+  // coupled record (14 words): rT(3) torso frame, rB(3) block frame, nW(3) world normal robot->block, An, Bt1, Bt2, D, meta.
+  // fw = world contact frame (normal + MuJoCo's mju_makeFrame tangents), built once per patch by the caller.
+  static BRS_HD void add_coupled(const Params<R>& P, Store<R>& st, Frame& F, const ES& S, const R* rT, const R* fw, R dist,
+                                 int sel, bool share) {
     if (F.nc >= N_COUPLED_SLOTS) return;
     const ContactClass<R>& c = P.cc[CC_BLOCK_ROBOT];
-    R fw[9], pw[3], rB[3], wc[3], t[3];
-    mul_(F.RT, nTf, fw);
-    R il = rsqrt_(dot_(fw, fw));
-    fw[0] *= il; fw[1] *= il; fw[2] *= il;
-    make_frame(fw);
+    R pw[3], rB[3], wc[3], t[3];
     mul_(F.RT, rT, pw);
     pw[0] += F.dTB[0]; pw[1] += F.dTB[1]; pw[2] += F.dTB[2];
     mulT_(F.RB, pw, rB);
@@ -567,8 +588,12 @@ template <typename R, bool BLK> struct Sim {
     st.setc(k, 10, -c.B * c.mu * vt1);
     st.setc(k, 11, -c.B * c.mu * vt2);
     st.setc(k, 12, imp * rcp_((1 - imp) * cD));
-    st.setc(k, 13, (R)hint_meta(st.getc(k, 13), sel, k < F.pnc));
+    st.setc(k, 13, (R)(hint_meta(st.getc(k, 13), sel, k < F.pnc) | (share && k > 0 ? META_SHARE : 0)));
     F.nc++;
+  }
+  static BRS_HD void world_frame(const Frame& F, const R* nTf, R* fw) {  // unit normal in the torso frame -> world contact frame
+    mul_(F.RT, nTf, fw);
+    make_frame(fw);
   }
   // everything in the TORSO frame: block centre cB, block axes as columns of RTB = RT^T RB
   static BRS_HD void collide_coupled(const Params<R>& P, Store<R>& st, Frame& F, const ES& S) {
@@ -585,6 +610,7 @@ template <typename R, bool BLK> struct Sim {
 #pragma unroll
       for (int j = 0; j < 3; j++) RTB[3 * i + j] = F.RT[i] * F.RB[j] + F.RT[3 + i] * F.RB[3 + j] + F.RT[6 + i] * F.RB[6 + j];
     R s = P.block_s;
+    BRS_TIC(10);
     // (i) torso box <-> block box (OWN generator, mirrored in oracle/brs_oracle.c box_box_own): SAT over the 6 face
     // axes, reference face = minimum overlap, contacts = incident-face vertices behind it and inside its rectangle,
     // else the deepest incident vertex clamped into the rectangle.  <= 4 points.  No runtime-indexed arrays.
@@ -611,8 +637,10 @@ template <typename R, bool BLK> struct Sim {
         if (ov < best) { best = ov; bestax = 3 + j; }
       }
       if (!sep) {
-        int cnt = 0;
-        R fb_dist = (R)1e30, fb_pos[3] = {0, 0, 0}, nrm[3];
+        // candidates of the incident face first (cheap, case-specific), insertion afterwards in ONE uniform loop
+        R cpos[4][3], cdist[4], nrm[3];
+        bool cval[4];
+        R fb_dist = (R)1e30, fb_pos[3] = {0, 0, 0};
         if (bestax < 3) {
           const int k = bestax;
           R sg = pick3(k, cg) >= 0 ? (R)1 : (R)-1;
@@ -636,21 +664,15 @@ template <typename R, bool BLK> struct Sim {
             bool lat = true;
 #pragma unroll
             for (int i = 0; i < 3; i++) lat = lat && (i == k || abs_(p[i]) <= sT[i] + c.margin);
-            if (dist < c.margin && lat) {
-              R pos[3] = {p[0] - nrm[0] * dist * (R)0.5, p[1] - nrm[1] * dist * (R)0.5, p[2] + P.torso_cz - nrm[2] * dist * (R)0.5};
-              add_coupled(P, st, F, S, pos, nrm, dist, 0);
-              cnt++;
-            }
+            cval[v] = dist < c.margin && lat;
+            cdist[v] = dist;
+#pragma unroll
+            for (int i = 0; i < 3; i++) cpos[v][i] = p[i] - nrm[i] * dist * (R)0.5;
             if (dist < fb_dist) {
               fb_dist = dist;
 #pragma unroll
-              for (int i = 0; i < 3; i++) fb_pos[i] = i == k ? p[i] : max_(-sT[i], min_(sT[i], p[i]));
+              for (int i = 0; i < 3; i++) fb_pos[i] = (i == k ? p[i] : max_(-sT[i], min_(sT[i], p[i]))) - nrm[i] * dist * (R)0.5;
             }
-          }
-          if (cnt == 0 && fb_dist < c.margin) {
-            R pos[3] = {fb_pos[0] - nrm[0] * fb_dist * (R)0.5, fb_pos[1] - nrm[1] * fb_dist * (R)0.5,
-                        fb_pos[2] + P.torso_cz - nrm[2] * fb_dist * (R)0.5};
-            add_coupled(P, st, F, S, pos, nrm, fb_dist, 0);
           }
         } else {
           const int j = bestax - 3;
@@ -675,11 +697,10 @@ template <typename R, bool BLK> struct Sim {
             bool lat = true;
 #pragma unroll
             for (int i = 0; i < 3; i++) lat = lat && (i == j || abs_(pB[i]) <= s + c.margin);
-            if (dist < c.margin && lat) {
-              R pos[3] = {loc[0] + nrm[0] * dist * (R)0.5, loc[1] + nrm[1] * dist * (R)0.5, loc[2] + P.torso_cz + nrm[2] * dist * (R)0.5};
-              add_coupled(P, st, F, S, pos, nrm, dist, 0);
-              cnt++;
-            }
+            cval[v] = dist < c.margin && lat;
+            cdist[v] = dist;
+#pragma unroll
+            for (int i = 0; i < 3; i++) cpos[v][i] = loc[i] + nrm[i] * dist * (R)0.5;
             if (dist < fb_dist) {
               R q[3], back[3];
 #pragma unroll
@@ -687,17 +708,32 @@ template <typename R, bool BLK> struct Sim {
               mul_(RTB, q, back);
               fb_dist = dist;
 #pragma unroll
-              for (int i = 0; i < 3; i++) fb_pos[i] = back[i] + cg[i];
+              for (int i = 0; i < 3; i++) fb_pos[i] = back[i] + cg[i] + nrm[i] * dist * (R)0.5;
             }
           }
-          if (cnt == 0 && fb_dist < c.margin) {
-            R pos[3] = {fb_pos[0] + nrm[0] * fb_dist * (R)0.5, fb_pos[1] + nrm[1] * fb_dist * (R)0.5,
-                        fb_pos[2] + P.torso_cz + nrm[2] * fb_dist * (R)0.5};
-            add_coupled(P, st, F, S, pos, nrm, fb_dist, 0);
+        }
+        if (!(cval[0] || cval[1] || cval[2] || cval[3]) && fb_dist < c.margin) {  // no vertex inside the rectangle: clamped deepest one
+          cval[0] = true; cdist[0] = fb_dist;
+#pragma unroll
+          for (int i = 0; i < 3; i++) cpos[0][i] = fb_pos[i];
+        }
+        if (cval[0] || cval[1] || cval[2] || cval[3]) {
+          R fw[9];
+          world_frame(F, nrm, fw);  // one contact frame for the whole patch
+          bool first_in_patch = true;
+#pragma unroll
+          for (int v = 0; v < 4; v++) {
+            if (cval[v]) {
+              R pos[3] = {cpos[v][0], cpos[v][1], cpos[v][2] + P.torso_cz};
+              add_coupled(P, st, F, S, pos, fw, cdist[v], 0, !first_in_patch);
+              first_in_patch = false;
+            }
           }
         }
       }
     }
+    BRS_TOC(10);
+    BRS_TIC(11);
     // (ii) wheel cylinder <-> block box: single deepest candidate per wheel
 #pragma unroll
     for (int wsel = 1; wsel <= 2; wsel++) {
@@ -745,8 +781,13 @@ template <typename R, bool BLK> struct Sim {
           }
         }
       }
-      if (found) add_coupled(P, st, F, S, bpos, bn, best, wsel);
+      if (found) {
+        R fw[9];
+        world_frame(F, bn, fw);
+        add_coupled(P, st, F, S, bpos, fw, best, wsel, false);
+      }
     }
+    BRS_TOC(11);
   }
 
   // per-pass data of one coupled contact: frame axes (n,t1,t2) rotated into both body frames
@@ -755,17 +796,20 @@ template <typename R, bool BLK> struct Sim {
     R An, Bt1, Bt2, D, mu;
     int sel, meta;
   };
+  // C persists across the contacts of one pass: a contact flagged META_SHARE reuses the frame rows of its predecessor
   static BRS_HD void coupled_load(const Params<R>& P, const Store<R>& st, const Frame& F, int c, Coupled& C) {
-    R fw[9];
 #pragma unroll
-    for (int j = 0; j < 3; j++) { C.rT[j] = st.getc(c, j); C.rB[j] = st.getc(c, 3 + j); fw[j] = st.getc(c, 6 + j); }
+    for (int j = 0; j < 3; j++) { C.rT[j] = st.getc(c, j); C.rB[j] = st.getc(c, 3 + j); }
     C.An = st.getc(c, 9); C.Bt1 = st.getc(c, 10); C.Bt2 = st.getc(c, 11); C.D = st.getc(c, 12);
     C.meta = (int)st.getc(c, 13);
     C.sel = meta_sel(C.meta);
     C.mu = P.cc[CC_BLOCK_ROBOT].mu;
-    make_frame(fw);
+    if (!(C.meta & META_SHARE)) {
+      R fw[9] = {st.getc(c, 6), st.getc(c, 7), st.getc(c, 8), 0, 0, 0, 0, 0, 0};
+      make_frame(fw);
 #pragma unroll
-    for (int k = 0; k < 3; k++) { mulT_(F.RT, fw + 3 * k, C.dT[k]); mulT_(F.RB, fw + 3 * k, C.dB[k]); }
+      for (int k = 0; k < 3; k++) { mulT_(F.RT, fw + 3 * k, C.dT[k]); mulT_(F.RB, fw + 3 * k, C.dB[k]); }
+    }
     wheel_col(P, C.sel, C.rT, C.wc);
   }
 
@@ -807,11 +851,14 @@ template <typename R, bool BLK> struct Sim {
       return mk;
     }
 
-    // pass A: cost, constraint force J^T f and active-row masks at x; same = every mask equals the one H was built with
+    // pass A: active-row masks at x (same = every mask equals the one H was built with) and, when FORCES, also the cost
+    // and the constraint force J^T f.  The verify-only form is what the common path runs: at a point that reproduces its
+    // active set the constraint force is M (x - a0) exactly, no need to accumulate it contact by contact.
+    template <bool FORCES>
     static BRS_HD void passA(const Params<R>& P, Store<R>& st, const Frame& F, const R* x, const R* a0, R& cost, R* fcon,
-                             bool& same, bool want_cost) {
+                             bool& same) {
       R Md[NN], cst = 0, l[4];
-      if (want_cost) gauss(P, x, a0, Md, cst);  // the cost only steers the damped fallback (iterations >= BRS_UNDAMPED_ITERS)
+      if constexpr (FORCES) gauss(P, x, a0, Md, cst);  // the cost only steers the damped fallback
 #pragma unroll
       for (int i = 0; i < NN; i++) fcon[i] = 0;
       bool sm = true;
@@ -827,15 +874,17 @@ template <typename R, bool BLK> struct Sim {
         R xs = sel == 1 ? x[6] : (sel == 2 ? x[7] : (R)0);
         R pa[3] = {x[0] + t[0] + xs * wc[0], x[1] + t[1] + xs * wc[1], x[2] + t[2] + xs * wc[2]};
         int mk = rows_(dot_(F.nT, pa) - An, mu * dot_(F.t1T, pa) - Bt1, mu * dot_(F.t2T, pa) - Bt2, D, cst, l, meta_h(meta), sm);
-        R fn = D * (l[0] + l[1] + l[2] + l[3]), f1 = D * mu * (l[0] - l[1]), f2 = D * mu * (l[2] - l[3]);
-        R fb[3] = {F.nT[0] * fn + F.t1T[0] * f1 + F.t2T[0] * f2, F.nT[1] * fn + F.t1T[1] * f1 + F.t2T[1] * f2,
-                   F.nT[2] * fn + F.t1T[2] * f1 + F.t2T[2] * f2};
-        cross_(r, fb, t);
-        fcon[0] += fb[0]; fcon[1] += fb[1]; fcon[2] += fb[2];
-        fcon[3] += t[0]; fcon[4] += t[1]; fcon[5] += t[2];
-        R fw = dot_(wc, fb);
-        fcon[6] += sel == 1 ? fw : (R)0;
-        fcon[7] += sel == 2 ? fw : (R)0;
+        if constexpr (FORCES) {
+          R fn = D * (l[0] + l[1] + l[2] + l[3]), f1 = D * mu * (l[0] - l[1]), f2 = D * mu * (l[2] - l[3]);
+          R fb[3] = {F.nT[0] * fn + F.t1T[0] * f1 + F.t2T[0] * f2, F.nT[1] * fn + F.t1T[1] * f1 + F.t2T[1] * f2,
+                     F.nT[2] * fn + F.t1T[2] * f1 + F.t2T[2] * f2};
+          cross_(r, fb, t);
+          fcon[0] += fb[0]; fcon[1] += fb[1]; fcon[2] += fb[2];
+          fcon[3] += t[0]; fcon[4] += t[1]; fcon[5] += t[2];
+          R fw = dot_(wc, fb);
+          fcon[6] += sel == 1 ? fw : (R)0;
+          fcon[7] += sel == 2 ? fw : (R)0;
+        }
         st.set(s, 7, (R)meta_make(sel, mk, meta_h(meta)));
       }
       if constexpr (BLK) {
@@ -849,16 +898,18 @@ template <typename R, bool BLK> struct Sim {
           cross_(x + 11, r, t);
           R pa[3] = {x[8] + t[0], x[9] + t[1], x[10] + t[2]};
           int mk = rows_(dot_(F.nB, pa) - An, mu * dot_(F.t1B, pa) - Bt1, mu * dot_(F.t2B, pa) - Bt2, D, cst, l, meta_h(meta), sm);
-          R fn = D * (l[0] + l[1] + l[2] + l[3]), f1 = D * mu * (l[0] - l[1]), f2 = D * mu * (l[2] - l[3]);
-          R fb[3] = {F.nB[0] * fn + F.t1B[0] * f1 + F.t2B[0] * f2, F.nB[1] * fn + F.t1B[1] * f1 + F.t2B[1] * f2,
-                     F.nB[2] * fn + F.t1B[2] * f1 + F.t2B[2] * f2};
-          cross_(r, fb, t);
-          fcon[8] += fb[0]; fcon[9] += fb[1]; fcon[10] += fb[2];
-          fcon[11] += t[0]; fcon[12] += t[1]; fcon[13] += t[2];
+          if constexpr (FORCES) {
+            R fn = D * (l[0] + l[1] + l[2] + l[3]), f1 = D * mu * (l[0] - l[1]), f2 = D * mu * (l[2] - l[3]);
+            R fb[3] = {F.nB[0] * fn + F.t1B[0] * f1 + F.t2B[0] * f2, F.nB[1] * fn + F.t1B[1] * f1 + F.t2B[1] * f2,
+                       F.nB[2] * fn + F.t1B[2] * f1 + F.t2B[2] * f2};
+            cross_(r, fb, t);
+            fcon[8] += fb[0]; fcon[9] += fb[1]; fcon[10] += fb[2];
+            fcon[11] += t[0]; fcon[12] += t[1]; fcon[13] += t[2];
+          }
             st.set(s, 7, (R)meta_make(3, mk, meta_h(meta)));
         }
+        Coupled C;
         for (int c = 0; c < F.nc; c++) {
-          Coupled C;
           coupled_load(P, st, F, c, C);
           R t[3];
           cross_(x + 3, C.rT, t);
@@ -868,23 +919,25 @@ template <typename R, bool BLK> struct Sim {
           R paB[3] = {x[8] + t[0], x[9] + t[1], x[10] + t[2]};
           int mk = rows_(dot_(C.dB[0], paB) - dot_(C.dT[0], paT) - C.An, C.mu * (dot_(C.dB[1], paB) - dot_(C.dT[1], paT)) - C.Bt1,
                          C.mu * (dot_(C.dB[2], paB) - dot_(C.dT[2], paT)) - C.Bt2, C.D, cst, l, meta_h(C.meta), sm);
-          R fn = C.D * (l[0] + l[1] + l[2] + l[3]), f1 = C.D * C.mu * (l[0] - l[1]), f2 = C.D * C.mu * (l[2] - l[3]);
-          R fT[3], fB[3];
-#pragma unroll
-          for (int j = 0; j < 3; j++) {
-            fT[j] = -(C.dT[0][j] * fn + C.dT[1][j] * f1 + C.dT[2][j] * f2);
-            fB[j] = C.dB[0][j] * fn + C.dB[1][j] * f1 + C.dB[2][j] * f2;
+          if constexpr (FORCES) {
+            R fn = C.D * (l[0] + l[1] + l[2] + l[3]), f1 = C.D * C.mu * (l[0] - l[1]), f2 = C.D * C.mu * (l[2] - l[3]);
+            R fT[3], fB[3];
+  #pragma unroll
+            for (int j = 0; j < 3; j++) {
+              fT[j] = -(C.dT[0][j] * fn + C.dT[1][j] * f1 + C.dT[2][j] * f2);
+              fB[j] = C.dB[0][j] * fn + C.dB[1][j] * f1 + C.dB[2][j] * f2;
+            }
+            cross_(C.rT, fT, t);
+            fcon[0] += fT[0]; fcon[1] += fT[1]; fcon[2] += fT[2];
+            fcon[3] += t[0]; fcon[4] += t[1]; fcon[5] += t[2];
+            R fw = dot_(C.wc, fT);
+            fcon[6] += C.sel == 1 ? fw : (R)0;
+            fcon[7] += C.sel == 2 ? fw : (R)0;
+            cross_(C.rB, fB, t);
+            fcon[8] += fB[0]; fcon[9] += fB[1]; fcon[10] += fB[2];
+            fcon[11] += t[0]; fcon[12] += t[1]; fcon[13] += t[2];
           }
-          cross_(C.rT, fT, t);
-          fcon[0] += fT[0]; fcon[1] += fT[1]; fcon[2] += fT[2];
-          fcon[3] += t[0]; fcon[4] += t[1]; fcon[5] += t[2];
-          R fw = dot_(C.wc, fT);
-          fcon[6] += C.sel == 1 ? fw : (R)0;
-          fcon[7] += C.sel == 2 ? fw : (R)0;
-          cross_(C.rB, fB, t);
-          fcon[8] += fB[0]; fcon[9] += fB[1]; fcon[10] += fB[2];
-          fcon[11] += t[0]; fcon[12] += t[1]; fcon[13] += t[2];
-          st.setc(c, 13, (R)meta_make(C.sel, mk, meta_h(C.meta)));
+          st.setc(c, 13, (R)(meta_make(C.sel, mk, meta_h(C.meta)) | (C.meta & META_SHARE)));
         }
       }
       cost = cst;
@@ -987,8 +1040,8 @@ template <typename R, bool BLK> struct Sim {
                                       meta_new(meta), x2);
           st.set(s, 7, (R)meta_make(3, mk, mk));
         }
+        Coupled C;
         for (int c = 0; c < F.nc; c++) {
-          Coupled C;
           coupled_load(P, st, F, c, C);
           V2<R> g[3][7];
 #pragma unroll
@@ -1003,7 +1056,7 @@ template <typename R, bool BLK> struct Sim {
           }
           int mk = contact_into<0, 7>(H, rhs2, g[0], g[1], g[2], C.mu, C.D, C.An, C.Bt1, C.Bt2, first && meta_h(C.meta) != 17,
                                       meta_new(C.meta), x2);
-          st.setc(c, 13, (R)meta_make(C.sel, mk, mk));
+          st.setc(c, 13, (R)(meta_make(C.sel, mk, mk) | (C.meta & META_SHARE)));
         }
       }
     }
@@ -1018,17 +1071,30 @@ template <typename R, bool BLK> struct Sim {
       bool same;
       BRS_STAT(stats().iters[0]++; stats().last_iters[0]++);
       BRS_MARK("iter_assemble");
+      BRS_TIC(4);
       assemble(P, st, F, x, a0, first, H, rhs2);
       first = false;
+      for (int i_ = 0; i_ < NP; i_++) { BRS_PIN(rhs2[i_].x); BRS_PIN(rhs2[i_].y); }
+      for (int i_ = 0; i_ < NH2; i_++) { BRS_PIN(H[i_].x); BRS_PIN(H[i_].y); }
+      BRS_TOC(4);
+      BRS_TIC(5);
       BRS_MARK("iter_chol");
 #pragma unroll
       for (int k = 0; k < NP; k++) { rhs[2 * k] = rhs2[k].x; if (2 * k + 1 < NN) rhs[2 * k + 1] = rhs2[k].y; }
 #pragma unroll
       for (int i = 0; i < NN; i++) xn[i] = 0;
       chol_solve_packed<R, NN>(H, rhs, xn);
+      for (int i_ = 0; i_ < NN; i_++) BRS_PIN(xn[i_]);
+      BRS_TOC(5);
+      BRS_TIC(6);
       BRS_MARK("iter_passA");
-      const bool damped = it + 1 >= BRS_UNDAMPED_ITERS;  // the next iteration may need this point's cost
-      passA(P, st, F, xn, a0, ct, ft, same, damped);
+      const bool lite = it + 1 < BRS_UNDAMPED_ITERS;  // the damped fallback needs costs and forces at every point
+      if (lite) {
+        passA<false>(P, st, F, xn, a0, ct, ft, same);
+        gauss(P, xn, a0, ft, ct);  // ft = M (xn - a0): the constraint force if xn reproduces its active set
+      } else
+        passA<true>(P, st, F, xn, a0, ct, ft, same);
+      BRS_TOC(6);
       BRS_MARK("iter_tail");
       bool full = true;
       // pure active-set iteration for the first sweeps (it terminates at once in ~97% of the substeps); if it has not
@@ -1038,7 +1104,7 @@ template <typename R, bool BLK> struct Sim {
         BRS_STAT(stats().backtracks[0]++);
 #pragma unroll
         for (int i = 0; i < NN; i++) xn[i] = x[i] + (R)0.5 * (xn[i] - x[i]);
-        passA(P, st, F, xn, a0, ct, ft, same, true);
+        passA<true>(P, st, F, xn, a0, ct, ft, same);
       }
       cost = ct;
 #pragma unroll
@@ -1062,6 +1128,7 @@ template <typename R, bool BLK> struct Sim {
     Frame& F = C.F;
     R* f = C.f;
     BRS_MARK("begin_kin");
+    BRS_TIC(0);
     // kinematics
     R qf[4] = {(R)S.q[0], (R)S.q[1], (R)S.q[2], (R)S.q[3]};
     quat2mat_(qf, F.RT);
@@ -1090,6 +1157,10 @@ template <typename R, bool BLK> struct Sim {
     f[6] = fL - P.damping * S.ww[0];
     f[7] = fR - P.damping * S.ww[1];
     msolve0_(P, f, F.a0);
+    for (int i_ = 0; i_ < 8; i_++) { BRS_PIN(F.a0[i_]); BRS_PIN(f[i_]); }
+    BRS_PIN(u[0]); BRS_PIN(u[1]); BRS_PIN(u[2]); BRS_PIN(zT);
+    BRS_TOC(0);
+    BRS_TIC(1);
     BRS_MARK("begin_collide_robot");
     // collision: robot <-> floor.  Slot priority: wheel main points, torso corners, wheel triangle points
     F.nfr = 0; F.nfb = 0; F.nc = 0;
@@ -1099,6 +1170,7 @@ template <typename R, bool BLK> struct Sim {
     collide_torso(P, st, F, u, S.w, S.ww, zT);
     collide_wheel(P, st, F, u, S.w, S.ww, zT, 1, true);
     collide_wheel(P, st, F, u, S.w, S.ww, zT, 2, true);
+    BRS_TOC(1);
     if constexpr (BLK) {
       R qb[4] = {(R)S.bq[0], (R)S.bq[1], (R)S.bq[2], (R)S.bq[3]};
       quat2mat_(qb, F.RB);
@@ -1113,14 +1185,18 @@ template <typename R, bool BLK> struct Sim {
         F.a0[8 + i] = -P.g * F.nB[i];
         F.a0[11 + i] = 0;
       }
+      BRS_TIC(2);
       BRS_MARK("begin_collide_blockfloor");
 #ifndef BRS_NO_BLOCKFLOOR
       collide_block_floor(P, st, F, uB, S.bw, zB);
 #endif
+      BRS_TOC(2);
+      BRS_TIC(3);
       BRS_MARK("begin_collide_coupled");
 #ifndef BRS_NO_COUPLED
       collide_coupled(P, st, F, S);
 #endif
+      BRS_TOC(3);
     }
     S.pnfr = F.nfr; S.pnfb = F.nfb; S.pnc = F.nc;
     BRS_MARK("begin_tail");
@@ -1137,6 +1213,7 @@ template <typename R, bool BLK> struct Sim {
   }
   static BRS_HD void sub_end(const Params<R>& P, ES& S, SubCtx& C) {
     BRS_MARK("end_integrate");
+    BRS_TIC(7);
     const Frame& F = C.F;
     const R* f = C.f;
     const R* fcon = C.fcon;
@@ -1170,6 +1247,10 @@ template <typename R, bool BLK> struct Sim {
       quat_advance(S.bq, (double)S.bw[0], (double)S.bw[1], (double)S.bw[2], P.h_d);
     }
     S.time += P.h_d;
+    for (int i_ = 0; i_ < 3; i_++) { BRS_PIN(S.v[i_]); BRS_PIN(S.w[i_]); BRS_PIN(S.p[i_]); }
+    for (int i_ = 0; i_ < 4; i_++) BRS_PIN(S.q[i_]);
+    BRS_PIN(S.ww[0]); BRS_PIN(S.ww[1]);
+    BRS_TOC(7);
     BRS_MARK("end_done");
   }
   // un-flattened form (one lane at a time: host tests, single substeps)

@@ -20,6 +20,10 @@
 #include <vector>
 
 #include "../../include/brs.h"
+#if defined(BRS_TIMING)
+__device__ unsigned long long brs_dbg[16];
+#define BRS_TIMING_LANE_WORDS 152
+#endif
 #include "brs_state.hpp"
 
 using namespace brs;
@@ -39,16 +43,23 @@ __global__ void __launch_bounds__(256) brs_step_kernel(const Params<float> P, co
                                                        const float* __restrict__ actions, float* __restrict__ obs,
                                                        float* __restrict__ reward, uint8_t* __restrict__ terminated,
                                                        uint8_t* __restrict__ truncated, float* __restrict__ terminal_obs) {
-  extern __shared__ float lds[];
+  extern __shared__ float brs_lds_dyn[];
+  float* lds = brs_lds_dyn;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;  // no barriers anywhere: a partial last wave just masks lanes
   Store<float> st = lane_store<BLK>(lds);
+#if defined(BRS_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+  if ((threadIdx.x & 63) == 0) for (int k = 0; k < 16; k++) brs_tim_slots()[k] = 0;
+#endif
   Stream<float> rng;
   rng.open(P.seed, P.gid_base + (int64_t)i, 0u);
   const float a0 = actions[2 * (size_t)i], a1 = actions[2 * (size_t)i + 1];
   float o[6], to[6], rew;
   int te, tr;
   env_step_mem<float, BLK, float>(P, st, rng, d, f, ii, (size_t)N, (size_t)i, a0, a1, o, to, rew, te, tr);
+#if defined(BRS_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+  if ((threadIdx.x & 63) == 0) for (int k = 0; k < 16; k++) atomicAdd(&brs_dbg[k], brs_tim_slots()[k]);
+#endif
 #pragma unroll
   for (int k = 0; k < 6; k++) obs[6 * (size_t)i + k] = o[k];
   if (terminal_obs) {
@@ -83,7 +94,8 @@ template <bool BLK>
 __global__ void __launch_bounds__(256) brs_physics_kernel(const Params<float> P, const int N, double* __restrict__ d,
                                                           float* __restrict__ f, int* __restrict__ ii,
                                                           const float* __restrict__ ctrl, const int nsub) {
-  extern __shared__ float lds[];
+  extern __shared__ float brs_lds_dyn[];
+  float* lds = brs_lds_dyn;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   Store<float> st = lane_store<BLK>(lds);
@@ -129,7 +141,11 @@ int fail(brs_handle* h, int code, const std::string& msg) {
     if (e_ != hipSuccess) return fail(h, BRS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
   } while (0)
 
+#if defined(BRS_TIMING)
+size_t lds_bytes(const brs_handle* h) { return (size_t)h->bt * BRS_TIMING_LANE_WORDS * sizeof(float) + (size_t)(h->bt / 64) * 128; }
+#else
 size_t lds_bytes(const brs_handle* h) { return (size_t)h->bt * (h->blk ? LDS_WORDS_ENV03 : LDS_WORDS_ENV01) * sizeof(float); }
+#endif
 int grid_of(const brs_handle* h) { return (h->N + h->bt - 1) / h->bt; }
 
 template <bool BLK> int upload_state(brs_handle* h, const std::vector<double>& d, const std::vector<float>& f, const std::vector<int>& ii) {
@@ -310,6 +326,15 @@ int64_t brs_step_bytes_per_env(const brs_handle* h) {
   // state read + state written + action (8) + obs (24) + terminal obs (24) + reward (4) + two flags (2)
   return (int64_t)(2 * st + 8 + 24 + 24 + 4 + 2);
 }
+#if defined(BRS_TIMING)
+// diagnostic builds only: read and clear the per-phase cycle sums
+int brs_debug_counters(unsigned long long* out16) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(brs_dbg), 16 * sizeof(unsigned long long)) != hipSuccess) return BRS_ERR_HIP;
+  unsigned long long z[16] = {0};
+  if (hipMemcpyToSymbol(HIP_SYMBOL(brs_dbg), z, sizeof z) != hipSuccess) return BRS_ERR_HIP;
+  return BRS_OK;
+}
+#endif
 const char* brs_step_kernel_name(const brs_handle* h) {
   if (!h) return "";
   return h->blk ? "brs_step_kernel<true>" : "brs_step_kernel<false>";

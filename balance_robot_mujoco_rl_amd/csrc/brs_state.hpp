@@ -125,6 +125,7 @@ BRS_HD void env_step_mem(const Params<R>& P, Store<R>& st, Stream<R>& rng, doubl
     int k = 0;
     bool fresh = true;
     while (k < P.nsub) {
+      BRS_TIC(8);
       if (fresh) {
         if (k == P.nsub - 1) {
 #pragma unroll
@@ -141,6 +142,10 @@ BRS_HD void env_step_mem(const Params<R>& P, Store<R>& st, Stream<R>& rng, doubl
         k++;
         fresh = true;
       }
+      BRS_TOC(8);
+#if defined(BRS_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+      if ((threadIdx.x & 63) == 0) brs_tim_slots()[9] += 1ull;
+#endif
     }
   }
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-phase wave cycles of the step kernel (needs a -DBRS_TIMING build; run on the GPU box).
+    BRS_EXTRA_HIPCC_FLAGS=-DBRS_TIMING python tools/phase_timing.py [Env03-v2]"""
+import ctypes as C, os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("BRS_EXTRA_HIPCC_FLAGS", "-DBRS_TIMING")
+from balance_robot_mujoco_rl_amd import _lib
+_lib.build(force=True)
+from balance_robot_mujoco_rl_amd import BatchedSim
+env = sys.argv[1] if len(sys.argv) > 1 else "Env03-v2"
+n = 65536
+sim = BatchedSim(env, n, seed=0)
+sim.reset()
+L = _lib.lib()
+buf = (C.c_ulonglong * 16)()
+g = torch.Generator(device="cuda"); g.manual_seed(1234)
+acts = [torch.rand((n, 2), generator=g, device="cuda") * 2 - 1 for _ in range(16)]
+for k in range(60): sim.step(acts[k % 16])
+torch.cuda.synchronize(); L.brs_debug_counters(buf)
+steps = 60
+for k in range(steps): sim.step(acts[k % 16])
+torch.cuda.synchronize(); L.brs_debug_counters(buf)
+names = ["kin+smooth", "collide robot-floor", "collide block-floor", "collide coupled", "assemble", "cholesky", "passA/verify", "integrate", "whole trip", "trips", "  coupled: torso patch", "  coupled: wheels"]
+waves = n // 64
+tot = buf[8]
+print(f"{env}: trips per wave-step {buf[9] / waves / steps:.1f}")
+for i, nm in [(j, names[j]) for j in (0, 1, 2, 3, 10, 11, 4, 5, 6, 7, 8)]:
+    print(f"  {nm:22s} {buf[i] / waves / steps:12.0f} cycles/wave-step  {100.0 * buf[i] / tot:5.1f}% of trip time   {buf[i] / max(1, buf[9]):8.0f} cycles/trip")
