@@ -195,10 +195,10 @@ template <typename R> struct Stream {
 };
 
 // ------------------------------------------------------------------------------------ per-lane contact store
-// floor-contact slots hold 8 words, coupled slots 14; word k of the lane's column lives at base[k*stride]
+// floor-contact slots hold 7 words, coupled slots 13; word k of the lane's column lives at base[k*stride]
 // (GPU: stride 64 = one LDS row per word, consecutive lanes on consecutive banks)
-enum { SLOT_ROBOT = 0, N_ROBOT_SLOTS = 8, SLOT_BLOCK = 8, N_BLOCK_SLOTS = 4, N_COUPLED_SLOTS = 4, SLOT_WORDS = 8,
-       COUPLED_WORDS = 14, COUPLED_BASE = (N_ROBOT_SLOTS + N_BLOCK_SLOTS) * SLOT_WORDS,
+enum { SLOT_ROBOT = 0, N_ROBOT_SLOTS = 8, SLOT_BLOCK = 8, N_BLOCK_SLOTS = 4, N_COUPLED_SLOTS = 4, SLOT_WORDS = 7,
+       COUPLED_WORDS = 13, COUPLED_BASE = (N_ROBOT_SLOTS + N_BLOCK_SLOTS) * SLOT_WORDS,
        LDS_WORDS_ENV01 = N_ROBOT_SLOTS * SLOT_WORDS, LDS_WORDS_ENV03 = COUPLED_BASE + N_COUPLED_SLOTS * COUPLED_WORDS };
 template <typename R> struct Store {
   R* base;
@@ -208,23 +208,16 @@ template <typename R> struct Store {
   BRS_HD R getc(int c, int w) const { return base[(COUPLED_BASE + c * COUPLED_WORDS + w) * stride]; }
   BRS_HD void setc(int c, int w, R v) { base[(COUPLED_BASE + c * COUPLED_WORDS + w) * stride] = v; }
 };
-// meta word (kept as an exactly-representable small number): sel | maskNew<<2 | maskH<<6
-BRS_HD int meta_sel(int m) { return m & 3; }
-BRS_HD int meta_new(int m) { return (m >> 2) & 15; }
-BRS_HD int meta_h(int m) { return (m >> 6) & 31; }
-BRS_HD int meta_make(int sel, int mnew, int mh) { return sel | (mnew << 2) | (mh << 6); }
-BRS_HD constexpr int META_SHARE = 2048;  // coupled contacts: same normal (same contact frame) as the previous slot
-// a slot that held a contact of the same body in the previous substep keeps that contact's final active rows as the
-// first guess of this substep's active set (maskH = 17: guess present, H not built yet; 16: no guess)
-template <typename R> BRS_HD int hint_meta(R oldword, int sel, bool existed) {
-#if BRS_MASK_HINT
-  int old = (int)oldword;
-  bool ok = existed && meta_sel(old) == sel;
-  return meta_make(sel, ok ? meta_new(old) : 0, ok ? 17 : 16);
-#else
-  return meta_make(sel, 0, 16);
-#endif
-}
+// Per-lane bookkeeping of the contact lists lives in registers, not in LDS: 4-bit active-row masks packed 8 slots
+// to a word (R: robot<->floor slots 0..7; X: block<->floor 0..3 and block<->robot 4..7), body selectors 2 bits per slot.
+struct Masks { uint32_t hR, hX, nR, nX; };  // h: the masks H was built with; n: masks at the latest evaluated point
+BRS_HD int get4(uint32_t m, int slot) { return (int)((m >> (4 * slot)) & 15u); }
+BRS_HD uint32_t put4(int v, int slot) { return (uint32_t)v << (4 * slot); }
+// sels word: bits [0,16) robot<->floor body (0 torso, 1 L wheel, 2 R wheel), [16,24) block<->robot body, [24,28) "same
+// contact frame as the previous coupled slot"
+BRS_HD int sel_robot(uint32_t sels, int c) { return (int)((sels >> (2 * c)) & 3u); }
+BRS_HD int sel_coupled(uint32_t sels, int c) { return (int)((sels >> (16 + 2 * c)) & 3u); }
+BRS_HD bool share_coupled(uint32_t sels, int c) { return ((sels >> (24 + c)) & 1u) != 0; }
 
 // ------------------------------------------------------------------------------------ env state (registers)
 template <typename R, bool BLK> struct EnvState {
@@ -245,7 +238,8 @@ template <typename R, bool BLK> struct EnvState {
   int side_front;
   R ep_return;
   int bad;
-  int pnfr, pnfb, pnc;  // contact-list lengths of the previous substep (mask hints; not persisted across launches)
+  int pnfr, pnfb, pnc;  // previous substep: contact-list lengths, body selectors and final active-row masks -- the first
+  uint32_t psels, pmR, pmX;  // guess of this substep's active set (not persisted across launches)
 };
 
 template <typename R> BRS_HD R impedance_(const ContactClass<R>& c, R dist) {
@@ -420,6 +414,7 @@ template <typename R, bool BLK> struct Sim {
     R a0[NV];          // unconstrained acceleration (body coords)
     int nfr, nfb, nc;  // robot-floor, block-floor, coupled contact counts of this lane
     int pnfr, pnfb, pnc;  // the same of the previous substep
+    uint32_t sels, psels, pmR, pmX;
   };
 
   // wheel hinge column for a contact at r (torso frame) on wheel sel (1 L: axis -x at (-px,0,pz); 2 R: +x at (+px,0,pz))
@@ -448,7 +443,7 @@ template <typename R, bool BLK> struct Sim {
     st.set(s, 4, -c.B * c.mu * vt1);
     st.set(s, 5, -c.B * c.mu * vt2);
     st.set(s, 6, imp * rcp_((1 - imp) * c.cD));
-    st.set(s, 7, (R)hint_meta(st.get(s, 7), sel, F.nfr < F.pnfr));
+    F.sels |= (uint32_t)sel << (2 * F.nfr);
     F.nfr++;
   }
 
@@ -532,7 +527,6 @@ template <typename R, bool BLK> struct Sim {
         st.set(sl, 4, -c.B * c.mu * vt1);
         st.set(sl, 5, -c.B * c.mu * vt2);
         st.set(sl, 6, imp * rcp_((1 - imp) * c.cD));
-        st.set(sl, 7, (R)hint_meta(st.get(sl, 7), 3, F.nfb < F.pnfb));
         F.nfb++;
       }
     }
@@ -558,7 +552,7 @@ template <typename R, bool BLK> struct Sim {
     fw[3] *= il; fw[4] *= il; fw[5] *= il;
     cross_(fw, fw + 3, fw + 6);
   }
-  // coupled record (14 words): rT(3) torso frame, rB(3) block frame, nW(3) world normal robot->block, An, Bt1, Bt2, D, meta.
+  // coupled record (13 words): rT(3) torso frame, rB(3) block frame, nW(3) world normal robot->block, An, Bt1, Bt2, D.
   // fw = world contact frame (normal + MuJoCo's mju_makeFrame tangents), built once per patch by the caller.
   static BRS_HD void add_coupled(const Params<R>& P, Store<R>& st, Frame& F, const ES& S, const R* rT, const R* fw, R dist,
                                  int sel, bool share) {
@@ -588,7 +582,7 @@ template <typename R, bool BLK> struct Sim {
     st.setc(k, 10, -c.B * c.mu * vt1);
     st.setc(k, 11, -c.B * c.mu * vt2);
     st.setc(k, 12, imp * rcp_((1 - imp) * cD));
-    st.setc(k, 13, (R)(hint_meta(st.getc(k, 13), sel, k < F.pnc) | (share && k > 0 ? META_SHARE : 0)));
+    F.sels |= ((uint32_t)sel << (16 + 2 * k)) | ((share && k > 0) ? (1u << (24 + k)) : 0u);
     F.nc++;
   }
   static BRS_HD void world_frame(const Frame& F, const R* nTf, R* fw) {  // unit normal in the torso frame -> world contact frame
@@ -794,17 +788,16 @@ template <typename R, bool BLK> struct Sim {
   struct Coupled {
     R rT[3], rB[3], dT[3][3], dB[3][3], wc[3];
     R An, Bt1, Bt2, D, mu;
-    int sel, meta;
+    int sel;
   };
-  // C persists across the contacts of one pass: a contact flagged META_SHARE reuses the frame rows of its predecessor
+  // C persists across the contacts of one pass: a contact flagged "share" in F.sels reuses the frame rows of its predecessor
   static BRS_HD void coupled_load(const Params<R>& P, const Store<R>& st, const Frame& F, int c, Coupled& C) {
 #pragma unroll
     for (int j = 0; j < 3; j++) { C.rT[j] = st.getc(c, j); C.rB[j] = st.getc(c, 3 + j); }
     C.An = st.getc(c, 9); C.Bt1 = st.getc(c, 10); C.Bt2 = st.getc(c, 11); C.D = st.getc(c, 12);
-    C.meta = (int)st.getc(c, 13);
-    C.sel = meta_sel(C.meta);
+    C.sel = sel_coupled(F.sels, c);
     C.mu = P.cc[CC_BLOCK_ROBOT].mu;
-    if (!(C.meta & META_SHARE)) {
+    if (!share_coupled(F.sels, c)) {
       R fw[9] = {st.getc(c, 6), st.getc(c, 7), st.getc(c, 8), 0, 0, 0, 0, 0, 0};
       make_frame(fw);
 #pragma unroll
@@ -846,7 +839,7 @@ template <typename R, bool BLK> struct Sim {
       // its flip does not invalidate the quadratic piece H was built for
       R tol = (R)BRS_FLIP_TOL * (abs_(cn) + abs_(c1) + abs_(c2));
       int df = mk ^ mh;
-      if (((df & 1) && abs_(e1) > tol) || ((df & 2) && abs_(e2) > tol) || ((df & 4) && abs_(e3) > tol) || ((df & 8) && abs_(e4) > tol) || mh > 15)
+      if (((df & 1) && abs_(e1) > tol) || ((df & 2) && abs_(e2) > tol) || ((df & 4) && abs_(e3) > tol) || ((df & 8) && abs_(e4) > tol))
         sm = false;
       return mk;
     }
@@ -855,9 +848,10 @@ template <typename R, bool BLK> struct Sim {
     // and the constraint force J^T f.  The verify-only form is what the common path runs: at a point that reproduces its
     // active set the constraint force is M (x - a0) exactly, no need to accumulate it contact by contact.
     template <bool FORCES>
-    static BRS_HD void passA(const Params<R>& P, Store<R>& st, const Frame& F, const R* x, const R* a0, R& cost, R* fcon,
-                             bool& same) {
+    static BRS_HD void passA(const Params<R>& P, Store<R>& st, const Frame& F, Masks& M, const R* x, const R* a0, R& cost,
+                             R* fcon, bool& same) {
       R Md[NN], cst = 0, l[4];
+      M.nR = 0; M.nX = 0;
       if constexpr (FORCES) gauss(P, x, a0, Md, cst);  // the cost only steers the damped fallback
 #pragma unroll
       for (int i = 0; i < NN; i++) fcon[i] = 0;
@@ -866,14 +860,15 @@ template <typename R, bool BLK> struct Sim {
         int s = SLOT_ROBOT + c;
         R r[3] = {st.get(s, 0), st.get(s, 1), st.get(s, 2)};
         R An = st.get(s, 3), Bt1 = st.get(s, 4), Bt2 = st.get(s, 5), D = st.get(s, 6);
-        int meta = (int)st.get(s, 7), sel = meta_sel(meta);
+        int sel = sel_robot(F.sels, c);
         R mu = sel == 0 ? P.cc[CC_TORSO_FLOOR].mu : P.cc[CC_WHEEL_FLOOR].mu;
         R wc[3], t[3];
         wheel_col(P, sel, r, wc);
         cross_(x + 3, r, t);
         R xs = sel == 1 ? x[6] : (sel == 2 ? x[7] : (R)0);
         R pa[3] = {x[0] + t[0] + xs * wc[0], x[1] + t[1] + xs * wc[1], x[2] + t[2] + xs * wc[2]};
-        int mk = rows_(dot_(F.nT, pa) - An, mu * dot_(F.t1T, pa) - Bt1, mu * dot_(F.t2T, pa) - Bt2, D, cst, l, meta_h(meta), sm);
+        int mk = rows_(dot_(F.nT, pa) - An, mu * dot_(F.t1T, pa) - Bt1, mu * dot_(F.t2T, pa) - Bt2, D, cst, l, get4(M.hR, c), sm);
+        M.nR |= put4(mk, c);
         if constexpr (FORCES) {
           R fn = D * (l[0] + l[1] + l[2] + l[3]), f1 = D * mu * (l[0] - l[1]), f2 = D * mu * (l[2] - l[3]);
           R fb[3] = {F.nT[0] * fn + F.t1T[0] * f1 + F.t2T[0] * f2, F.nT[1] * fn + F.t1T[1] * f1 + F.t2T[1] * f2,
@@ -885,19 +880,18 @@ template <typename R, bool BLK> struct Sim {
           fcon[6] += sel == 1 ? fw : (R)0;
           fcon[7] += sel == 2 ? fw : (R)0;
         }
-        st.set(s, 7, (R)meta_make(sel, mk, meta_h(meta)));
       }
       if constexpr (BLK) {
         for (int c = 0; c < F.nfb; c++) {
           int s = SLOT_BLOCK + c;
           R r[3] = {st.get(s, 0), st.get(s, 1), st.get(s, 2)};
           R An = st.get(s, 3), Bt1 = st.get(s, 4), Bt2 = st.get(s, 5), D = st.get(s, 6);
-          int meta = (int)st.get(s, 7);
           R mu = P.cc[CC_BLOCK_FLOOR].mu;
           R t[3];
           cross_(x + 11, r, t);
           R pa[3] = {x[8] + t[0], x[9] + t[1], x[10] + t[2]};
-          int mk = rows_(dot_(F.nB, pa) - An, mu * dot_(F.t1B, pa) - Bt1, mu * dot_(F.t2B, pa) - Bt2, D, cst, l, meta_h(meta), sm);
+          int mk = rows_(dot_(F.nB, pa) - An, mu * dot_(F.t1B, pa) - Bt1, mu * dot_(F.t2B, pa) - Bt2, D, cst, l, get4(M.hX, c), sm);
+          M.nX |= put4(mk, c);
           if constexpr (FORCES) {
             R fn = D * (l[0] + l[1] + l[2] + l[3]), f1 = D * mu * (l[0] - l[1]), f2 = D * mu * (l[2] - l[3]);
             R fb[3] = {F.nB[0] * fn + F.t1B[0] * f1 + F.t2B[0] * f2, F.nB[1] * fn + F.t1B[1] * f1 + F.t2B[1] * f2,
@@ -906,7 +900,6 @@ template <typename R, bool BLK> struct Sim {
             fcon[8] += fb[0]; fcon[9] += fb[1]; fcon[10] += fb[2];
             fcon[11] += t[0]; fcon[12] += t[1]; fcon[13] += t[2];
           }
-            st.set(s, 7, (R)meta_make(3, mk, meta_h(meta)));
         }
         Coupled C;
         for (int c = 0; c < F.nc; c++) {
@@ -918,7 +911,8 @@ template <typename R, bool BLK> struct Sim {
           cross_(x + 11, C.rB, t);
           R paB[3] = {x[8] + t[0], x[9] + t[1], x[10] + t[2]};
           int mk = rows_(dot_(C.dB[0], paB) - dot_(C.dT[0], paT) - C.An, C.mu * (dot_(C.dB[1], paB) - dot_(C.dT[1], paT)) - C.Bt1,
-                         C.mu * (dot_(C.dB[2], paB) - dot_(C.dT[2], paT)) - C.Bt2, C.D, cst, l, meta_h(C.meta), sm);
+                         C.mu * (dot_(C.dB[2], paB) - dot_(C.dT[2], paT)) - C.Bt2, C.D, cst, l, get4(M.hX, 4 + c), sm);
+          M.nX |= put4(mk, 4 + c);
           if constexpr (FORCES) {
             R fn = C.D * (l[0] + l[1] + l[2] + l[3]), f1 = C.D * C.mu * (l[0] - l[1]), f2 = C.D * C.mu * (l[2] - l[3]);
             R fT[3], fB[3];
@@ -937,7 +931,6 @@ template <typename R, bool BLK> struct Sim {
             fcon[8] += fB[0]; fcon[9] += fB[1]; fcon[10] += fB[2];
             fcon[11] += t[0]; fcon[12] += t[1]; fcon[13] += t[2];
           }
-          st.setc(c, 13, (R)(meta_make(C.sel, mk, meta_h(C.meta)) | (C.meta & META_SHARE)));
         }
       }
       cost = cst;
@@ -988,8 +981,12 @@ template <typename R, bool BLK> struct Sim {
     }
 
     // assemble H = M + sum_active D j j^T and rhs = M a0 + sum_active D aref j  (both on the packed-pair layout)
-    static BRS_HD void assemble(const Params<R>& P, Store<R>& st, const Frame& F, const R* x, const R* a0, bool first,
+    static BRS_HD void assemble(const Params<R>& P, Store<R>& st, const Frame& F, Masks& M, const R* x, const R* a0, bool first,
                                 V2<R>* H, V2<R>* rhs2) {
+      // active rows of this piece: the latest evaluated masks; on the first iteration the previous substep's final
+      // masks where the slot held a contact of the same body then (else the rows are evaluated at x)
+      const uint32_t srcR = first ? F.pmR : M.nR, srcX = first ? F.pmX : M.nX;
+      M.hR = 0; M.hX = 0;
 #pragma unroll
       for (int i = 0; i < NH2; i++) H[i] = v2_splat<R>((R)0);
       h2_set(H, 0, 0, P.m); h2_set(H, 1, 1, P.m); h2_set(H, 2, 2, P.m);
@@ -1012,7 +1009,8 @@ template <typename R, bool BLK> struct Sim {
         int s = SLOT_ROBOT + c;
         R r[3] = {st.get(s, 0), st.get(s, 1), st.get(s, 2)};
         R An = st.get(s, 3), Bt1 = st.get(s, 4), Bt2 = st.get(s, 5), D = st.get(s, 6);
-        int meta = (int)st.get(s, 7), sel = meta_sel(meta);
+        int sel = sel_robot(F.sels, c);
+        const bool ev = first && !(BRS_MASK_HINT && c < F.pnfr && sel_robot(F.psels, c) == sel);
         R mu = sel == 0 ? P.cc[CC_TORSO_FLOOR].mu : P.cc[CC_WHEEL_FLOOR].mu;
         R wc[3], rn[3], r1[3], r2[3];
         wheel_col(P, sel, r, wc);
@@ -1022,23 +1020,22 @@ template <typename R, bool BLK> struct Sim {
         V2<R> gn[4] = {v2_make(F.nT[0], F.nT[1]), v2_make(F.nT[2], rn[0]), v2_make(rn[1], rn[2]), v2_make(zL * wn, zR * wn)};
         V2<R> g1[4] = {v2_make(F.t1T[0], F.t1T[1]), v2_make(F.t1T[2], r1[0]), v2_make(r1[1], r1[2]), v2_make(zL * w1, zR * w1)};
         V2<R> g2[4] = {v2_make(F.t2T[0], F.t2T[1]), v2_make(F.t2T[2], r2[0]), v2_make(r2[1], r2[2]), v2_make(zL * w2, zR * w2)};
-        int mk = contact_into<0, 4>(H, rhs2, gn, g1, g2, mu, D, An, Bt1, Bt2, first && meta_h(meta) != 17, meta_new(meta), x2);
-        st.set(s, 7, (R)meta_make(sel, mk, mk));
+        int mk = contact_into<0, 4>(H, rhs2, gn, g1, g2, mu, D, An, Bt1, Bt2, ev, get4(srcR, c), x2);
+        M.hR |= put4(mk, c);
       }
       if constexpr (BLK) {
         for (int c = 0; c < F.nfb; c++) {
           int s = SLOT_BLOCK + c;
           R r[3] = {st.get(s, 0), st.get(s, 1), st.get(s, 2)};
           R An = st.get(s, 3), Bt1 = st.get(s, 4), Bt2 = st.get(s, 5), D = st.get(s, 6);
-          int meta = (int)st.get(s, 7);
+          const bool ev = first && !(BRS_MASK_HINT && c < F.pnfb);
           R rn[3], r1[3], r2[3];
           cross_(r, F.nB, rn); cross_(r, F.t1B, r1); cross_(r, F.t2B, r2);
           V2<R> gn[3] = {v2_make(F.nB[0], F.nB[1]), v2_make(F.nB[2], rn[0]), v2_make(rn[1], rn[2])};
           V2<R> g1[3] = {v2_make(F.t1B[0], F.t1B[1]), v2_make(F.t1B[2], r1[0]), v2_make(r1[1], r1[2])};
           V2<R> g2[3] = {v2_make(F.t2B[0], F.t2B[1]), v2_make(F.t2B[2], r2[0]), v2_make(r2[1], r2[2])};
-          int mk = contact_into<4, 3>(H, rhs2, gn, g1, g2, P.cc[CC_BLOCK_FLOOR].mu, D, An, Bt1, Bt2, first && meta_h(meta) != 17,
-                                      meta_new(meta), x2);
-          st.set(s, 7, (R)meta_make(3, mk, mk));
+          int mk = contact_into<4, 3>(H, rhs2, gn, g1, g2, P.cc[CC_BLOCK_FLOOR].mu, D, An, Bt1, Bt2, ev, get4(srcX, c), x2);
+          M.hX |= put4(mk, c);
         }
         Coupled C;
         for (int c = 0; c < F.nc; c++) {
@@ -1054,9 +1051,9 @@ template <typename R, bool BLK> struct Sim {
             g[k][3] = v2_make(C.sel == 1 ? -wk : (R)0, C.sel == 2 ? -wk : (R)0);
             g[k][4] = v2_make(C.dB[k][0], C.dB[k][1]); g[k][5] = v2_make(C.dB[k][2], cb[0]); g[k][6] = v2_make(cb[1], cb[2]);
           }
-          int mk = contact_into<0, 7>(H, rhs2, g[0], g[1], g[2], C.mu, C.D, C.An, C.Bt1, C.Bt2, first && meta_h(C.meta) != 17,
-                                      meta_new(C.meta), x2);
-          st.setc(c, 13, (R)(meta_make(C.sel, mk, mk) | (C.meta & META_SHARE)));
+          const bool ev = first && !(BRS_MASK_HINT && c < F.pnc && sel_coupled(F.psels, c) == C.sel);
+          int mk = contact_into<0, 7>(H, rhs2, g[0], g[1], g[2], C.mu, C.D, C.An, C.Bt1, C.Bt2, ev, get4(srcX, 4 + c), x2);
+          M.hX |= put4(mk, 4 + c);
         }
       }
     }
@@ -1064,15 +1061,15 @@ template <typename R, bool BLK> struct Sim {
     // ONE Newton iteration at x (in/out); fcon out = J^T f at the new x.  Returns true when the new point is the
     // minimiser (a full step that reproduced its own active set) or the iteration cap is reached.
     // State carried by the caller across iterations of one substep: first (true on entry), it (0), cost.
-    static BRS_HD bool iterate(const Params<R>& P, Store<R>& st, const Frame& F, R* x, const R* a0, R* fcon, bool& first, int& it,
-                               R& cost) {
+    static BRS_HD bool iterate(const Params<R>& P, Store<R>& st, const Frame& F, Masks& M, R* x, const R* a0, R* fcon, bool& first,
+                               int& it, R& cost) {
       V2<R> H[NH2], rhs2[NP];
       R rhs[NN], xn[NN], ft[NN], ct;
       bool same;
       BRS_STAT(stats().iters[0]++; stats().last_iters[0]++);
       BRS_MARK("iter_assemble");
       BRS_TIC(4);
-      assemble(P, st, F, x, a0, first, H, rhs2);
+      assemble(P, st, F, M, x, a0, first, H, rhs2);
       first = false;
       for (int i_ = 0; i_ < NP; i_++) { BRS_PIN(rhs2[i_].x); BRS_PIN(rhs2[i_].y); }
       for (int i_ = 0; i_ < NH2; i_++) { BRS_PIN(H[i_].x); BRS_PIN(H[i_].y); }
@@ -1090,10 +1087,10 @@ template <typename R, bool BLK> struct Sim {
       BRS_MARK("iter_passA");
       const bool lite = it + 1 < BRS_UNDAMPED_ITERS;  // the damped fallback needs costs and forces at every point
       if (lite) {
-        passA<false>(P, st, F, xn, a0, ct, ft, same);
+        passA<false>(P, st, F, M, xn, a0, ct, ft, same);
         gauss(P, xn, a0, ft, ct);  // ft = M (xn - a0): the constraint force if xn reproduces its active set
       } else
-        passA<true>(P, st, F, xn, a0, ct, ft, same);
+        passA<true>(P, st, F, M, xn, a0, ct, ft, same);
       BRS_TOC(6);
       BRS_MARK("iter_tail");
       bool full = true;
@@ -1104,7 +1101,7 @@ template <typename R, bool BLK> struct Sim {
         BRS_STAT(stats().backtracks[0]++);
 #pragma unroll
         for (int i = 0; i < NN; i++) xn[i] = x[i] + (R)0.5 * (xn[i] - x[i]);
-        passA<true>(P, st, F, xn, a0, ct, ft, same);
+        passA<true>(P, st, F, M, xn, a0, ct, ft, same);
       }
       cost = ct;
 #pragma unroll
@@ -1123,6 +1120,7 @@ template <typename R, bool BLK> struct Sim {
     R f[8], fcon[NV], cost;
     bool clL, clR, conv, first;
     int it;
+    Masks M;
   };
   static BRS_HD void sub_begin(const Params<R>& P, Store<R>& st, ES& S, R ctrlL, R ctrlR, SubCtx& C) {
     Frame& F = C.F;
@@ -1165,6 +1163,7 @@ template <typename R, bool BLK> struct Sim {
     // collision: robot <-> floor.  Slot priority: wheel main points, torso corners, wheel triangle points
     F.nfr = 0; F.nfb = 0; F.nc = 0;
     F.pnfr = S.pnfr; F.pnfb = S.pnfb; F.pnc = S.pnc;
+    F.sels = 0; F.psels = S.psels; F.pmR = S.pmR; F.pmX = S.pmX;
     collide_wheel(P, st, F, u, S.w, S.ww, zT, 1, false);
     collide_wheel(P, st, F, u, S.w, S.ww, zT, 2, false);
     collide_torso(P, st, F, u, S.w, S.ww, zT);
@@ -1198,9 +1197,9 @@ template <typename R, bool BLK> struct Sim {
 #endif
       BRS_TOC(3);
     }
-    S.pnfr = F.nfr; S.pnfb = F.nfb; S.pnc = F.nc;
     BRS_MARK("begin_tail");
     C.first = true; C.it = 0; C.cost = 0;
+    C.M.hR = 0; C.M.hX = 0; C.M.nR = 0; C.M.nX = 0;
     C.conv = F.nfr + F.nfb + F.nc == 0;
     if (C.conv) {  // no contacts: the unconstrained acceleration is the answer
 #pragma unroll
@@ -1209,7 +1208,7 @@ template <typename R, bool BLK> struct Sim {
     BRS_STAT(if (!C.conv) { stats().solves[0]++; stats().last_iters[0] = 0; });
   }
   static BRS_HD void sub_iter(const Params<R>& P, Store<R>& st, ES& S, SubCtx& C) {
-    C.conv = Solver::iterate(P, st, C.F, S.a, C.F.a0, C.fcon, C.first, C.it, C.cost);
+    C.conv = Solver::iterate(P, st, C.F, C.M, S.a, C.F.a0, C.fcon, C.first, C.it, C.cost);
   }
   static BRS_HD void sub_end(const Params<R>& P, ES& S, SubCtx& C) {
     BRS_MARK("end_integrate");
@@ -1247,6 +1246,8 @@ template <typename R, bool BLK> struct Sim {
       quat_advance(S.bq, (double)S.bw[0], (double)S.bw[1], (double)S.bw[2], P.h_d);
     }
     S.time += P.h_d;
+    // first guess of the next substep's active set
+    S.pnfr = F.nfr; S.pnfb = F.nfb; S.pnc = F.nc; S.psels = F.sels; S.pmR = C.M.nR; S.pmX = C.M.nX;
     for (int i_ = 0; i_ < 3; i_++) { BRS_PIN(S.v[i_]); BRS_PIN(S.w[i_]); BRS_PIN(S.p[i_]); }
     for (int i_ = 0; i_ < 4; i_++) BRS_PIN(S.q[i_]);
     BRS_PIN(S.ww[0]); BRS_PIN(S.ww[1]);

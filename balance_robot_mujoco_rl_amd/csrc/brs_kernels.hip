@@ -22,7 +22,7 @@
 #include "../../include/brs.h"
 #if defined(BRS_TIMING)
 __device__ unsigned long long brs_dbg[16];
-#define BRS_TIMING_LANE_WORDS 152
+#define BRS_TIMING_LANE_WORDS 136
 #endif
 #include "brs_state.hpp"
 
