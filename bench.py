@@ -64,11 +64,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    backend = os.environ.get("BRS_BENCH_BACKEND", "nccl")  # "gloo" + BRS_BENCH_ONE_DEVICE=1: rehearse N ranks on one GPU
+    if os.environ.get("BRS_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
@@ -102,7 +108,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))  # HIP events on the launch stream
