@@ -10,10 +10,12 @@
 //   kinematics -> smooth forces (gravity/gyroscopic bias, wheel damping, clamped velocity servos)
 //   -> plane-cylinder / plane-box collision -> pyramidal-cone soft constraints (4 rows per contact)
 //   -> Newton solve of the convex acceleration problem -> implicitfast -> semi-implicit advance.
-// Formulation here (NOT MuJoCo's): the robot is a gyrostat; in body-frame linear coordinates its 8x8
-// mass matrix is CONSTANT and sparse (closed-form inverse); all floor contacts share the world-aligned
-// frame; the block (Env03) is an isotropic free body; robot and block systems are solved separately
-// (8x8 and 6x6 Cholesky in registers) unless a block<->robot contact couples them (14x14).
+// Formulation here (NOT MuJoCo's): the robot is a gyrostat; in body-frame linear coordinates its 8x8 mass matrix is
+// CONSTANT and sparse (closed-form inverse); all floor contacts share the world-aligned frame; the block (Env03) is an
+// isotropic free body.  One Newton solver over all dofs (8 or 14): every lane walks its own contact lists (robot<->floor,
+// block<->floor, block<->robot); H = M + G^T W G per contact on packed pairs (v_pk_fma_f32), packed Cholesky, exact
+// termination (a full step that reproduces its active set), previous-substep active sets as first guess.  The caller
+// flattens the substep loop and the Newton loop into one per-lane state machine (sub_begin / sub_iter / sub_end).
 #pragma once
 #include "brs_model.hpp"
 
@@ -60,9 +62,6 @@ __device__ __forceinline__ unsigned long long* brs_tim_slots() {  // 16 x u64 pe
 #endif
 #ifndef BRS_UNDAMPED_ITERS
 #define BRS_UNDAMPED_ITERS 3
-#endif
-#ifndef BRS_NEWTON_MODE
-#define BRS_NEWTON_MODE 1
 #endif
 
 namespace brs {

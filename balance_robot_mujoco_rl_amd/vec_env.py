@@ -195,3 +195,39 @@ class BalanceVecEnv(_VecEnvBase):
 
     def render(self, mode=None):
         return None  # no GL on the GPU box; the reference's viewer overlays are out of scope
+
+
+class BalanceVectorEnv:
+    """Gymnasium-style vector API over the same simulators: reset(seed) -> (obs, infos),
+    step(a) -> (obs, rewards, terminated, truncated, infos) with same-step auto-reset and infos["final_observation"] /
+    infos["_final_observation"] (gymnasium 0.29 convention).  Thin adapter over BalanceVecEnv."""
+
+    def __init__(self, env_id, num_envs, **kwargs):
+        self._v = BalanceVecEnv(env_id, num_envs, **kwargs)
+        self.num_envs = num_envs
+        self.single_observation_space, self.single_action_space = self._v.observation_space, self._v.action_space
+        self.observation_space, self.action_space = self.single_observation_space, self.single_action_space
+
+    def reset(self, seed=None, options=None):
+        return self._v.reset(), {}
+
+    def step(self, actions):
+        a = np.asarray(actions, dtype=np.float32).reshape(self.num_envs, 2)
+        v = self._v
+        v._pending = [s.step(a[st:st + cnt]) for s, (st, cnt) in zip(v._sims, v._ranges)]
+        obs, rew, term, trunc, tob = ([] for _ in range(5))
+        for o, r, te, tr, to in v._pending:
+            obs.append(v._to_numpy(o).copy()); rew.append(v._to_numpy(r).copy())
+            term.append(v._to_numpy(te).astype(bool)); trunc.append(v._to_numpy(tr).astype(bool)); tob.append(v._to_numpy(to).copy())
+        obs, rew, term, trunc, tob = (v._gather(x) for x in (obs, rew, term, trunc, tob))
+        done = term | trunc
+        infos = {}
+        if done.any():
+            final = np.empty(self.num_envs, dtype=object)
+            for i in np.flatnonzero(done):
+                final[i] = tob[i]
+            infos = {"final_observation": final, "_final_observation": done.copy()}
+        return obs, rew, term, trunc, infos
+
+    def close(self):
+        self._v.close()

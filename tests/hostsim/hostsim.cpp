@@ -27,7 +27,6 @@ struct IHost {
                          float* obs, float* rew, uint8_t* term, uint8_t* trunc, double* ctrl) = 0;
   virtual void script(int env, const double* u, int n) = 0;
   virtual int script_remaining(int env) const = 0;
-  virtual void contact_counts(int env, const double* ctrl, int* out) = 0;
 };
 
 template <typename R, bool BLK> struct HostSim : IHost {
@@ -135,15 +134,6 @@ template <typename R, bool BLK> struct HostSim : IHost {
   }
   void script(int env, const double* u, int n) override { scripts[env].assign(u, u + n); spos[env] = 0; }
   int script_remaining(int env) const override { return (int)scripts[env].size() - spos[env]; }
-  void contact_counts(int env, const double* ctrl, int* out) override {
-    // one throw-away substep on a copy, to look at the contact list sizes
-    R buf[LDS_WORDS_ENV03];
-    ES S;
-    load_state<R, BLK>(S, d.data(), f.data(), ii.data(), N, env);
-    Store<R> st{buf, 1};
-    (void)ctrl; (void)st; (void)S;
-    out[0] = out[1] = out[2] = -1;
-  }
 };
 
 extern "C" {

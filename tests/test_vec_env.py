@@ -99,3 +99,17 @@ def test_two_process_gloo_shards_match_single_process(tmp_path):
         act = rng.uniform(-1, 1, size=(n, 2)).astype(np.float32)
         ref.append(o.step(act)[0])
     np.testing.assert_array_equal(gathered, np.stack(ref))
+
+
+def test_gymnasium_style_vector_adapter():
+    from balance_robot_mujoco_rl_amd.vec_env import BalanceVectorEnv
+    n = 6
+    sims = [OracleSim("Env03-v2", cnt, seed=1, env_index_base=start, max_episode_steps=5) for start, cnt in shard_ranges(n, 2)]
+    env = BalanceVectorEnv("Env03-v2", n, _sims=sims)
+    obs, info = env.reset(seed=0)
+    assert obs.shape == (n, 6) and info == {}
+    for t in range(5):
+        obs, rew, term, trunc, infos = env.step(np.zeros((n, 2)))
+    assert trunc.all() and "final_observation" in infos and infos["_final_observation"].all()
+    assert infos["final_observation"][0].shape == (6,) and (obs[:, 1] == 0).all()
+    env.close()
