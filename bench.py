@@ -135,6 +135,16 @@ def main():
             "substeps_per_s": value * 250,
             "last_step_terminated": n_done,
         }
+        # HBM bytes per launch from the PMC counters cannot be collected from inside this process; when the committed
+        # rocprofv3 summary of this exact workload exists, report its per-launch figure (FETCH_SIZE x2 gfx950 correction
+        # + WRITE_SIZE, separate --pmc passes), else null
+        try:
+            if args.env == "Env03-v2" and n == 65536:
+                prof = json.load(open(os.path.join(ROOT, "profiles", "r01_env03_summary.json")))["hbm_traffic"]
+                out["roofline"]["traffic"] = prof["fetch_bytes_x2_corrected"] + prof["write_bytes"]
+                out["roofline"]["traffic_source"] = "profiles/r01_env03_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+        except Exception:
+            pass
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.env)
         print(json.dumps(out))
