@@ -406,9 +406,14 @@ template <typename R, bool BLK> struct Sim {
 
   // per-substep frame data shared by the passes
   struct Frame {
-    R RT[9];           // torso body->world
-    R nT[3], t1T[3], t2T[3];  // world +z, +y, -x expressed in the torso frame (floor contact frame)
-    R RB[9], nB[3], t1B[3], t2B[3];
+    R RT[9];           // torso body->world; its rows are the world axes in torso coordinates: the floor contact frame
+    R RB[9];           // is n = +z (row 2), t1 = +y (row 1), t2 = -x (minus row 0).  Same for the block.
+    BRS_HD const R* nT() const { return RT + 6; }
+    BRS_HD const R* t1T() const { return RT + 3; }
+    BRS_HD const R* xT() const { return RT; }
+    BRS_HD const R* nB() const { return RB + 6; }
+    BRS_HD const R* t1B() const { return RB + 3; }
+    BRS_HD const R* xB() const { return RB; }
     R dTB[3];          // x_T - x_B (world), for coupled contacts
     R a0[NV];          // unconstrained acceleration (body coords)
     int nfr, nfb, nc;  // robot-floor, block-floor, coupled contact counts of this lane
@@ -427,14 +432,14 @@ template <typename R, bool BLK> struct Sim {
                                      int sel, int cls, const R* pt, R dist) {
     if (F.nfr >= N_ROBOT_SLOTS) return;
     const ContactClass<R>& c = P.cc[cls];
-    R r[3] = {pt[0] - F.nT[0] * dist * (R)0.5, pt[1] - F.nT[1] * dist * (R)0.5, pt[2] - F.nT[2] * dist * (R)0.5};
+    R r[3] = {pt[0] - F.nT()[0] * dist * (R)0.5, pt[1] - F.nT()[1] * dist * (R)0.5, pt[2] - F.nT()[2] * dist * (R)0.5};
     // point velocity in the torso frame
     R wc[3], wr[3];
     wheel_col(P, sel, r, wc);
     cross_(w, r, wr);
     R wsel = sel == 1 ? ww[0] : (sel == 2 ? ww[1] : (R)0);
     R pv[3] = {u[0] + wr[0] + wsel * wc[0], u[1] + wr[1] + wsel * wc[1], u[2] + wr[2] + wsel * wc[2]};
-    R vn = dot_(F.nT, pv), vt1 = dot_(F.t1T, pv), vt2 = dot_(F.t2T, pv);
+    R vn = dot_(F.nT(), pv), vt1 = dot_(F.t1T(), pv), vt2 = -dot_(F.xT(), pv);
     R imp = impedance_(c, dist);
     int s = SLOT_ROBOT + F.nfr;
     st.set(s, 0, r[0]); st.set(s, 1, r[1]); st.set(s, 2, r[2]);
@@ -451,7 +456,7 @@ template <typename R, bool BLK> struct Sim {
                                    R zT, int sel, bool triangles) {
     const ContactClass<R>& c = P.cc[CC_WHEEL_FLOOR];
     R px = sel == 1 ? -P.wheel_px : P.wheel_px, pz = P.wheel_pz;
-    R nx = F.nT[0], ny = F.nT[1], nz = F.nT[2];
+    R nx = F.nT()[0], ny = F.nT()[1], nz = F.nT()[2];
     R len = sqrt_(ny * ny + nz * nz);
     R vy, vz;
     if (len >= (R)1e-15) { R k = P.wheel_r * rcp_(len); vy = -ny * k; vz = -nz * k; }
@@ -484,7 +489,7 @@ template <typename R, bool BLK> struct Sim {
   // plane <-> torso box: corners below the centre with dist < margin, at most 4 (MuJoCo's plane-box primitive)
   static BRS_HD void collide_torso(const Params<R>& P, Store<R>& st, Frame& F, const R* u, const R* w, const R* ww, R zT) {
     const ContactClass<R>& c = P.cc[CC_TORSO_FLOOR];
-    R nx = F.nT[0], ny = F.nT[1], nz = F.nT[2];
+    R nx = F.nT()[0], ny = F.nT()[1], nz = F.nT()[2];
     R dc = zT + nz * P.torso_cz;
     // cheap reject: lowest corner
     R low = dc - (abs_(nx) * P.torso_sx + abs_(ny) * P.torso_sy + abs_(nz) * P.torso_sz);
@@ -505,7 +510,7 @@ template <typename R, bool BLK> struct Sim {
 
   static BRS_HD void collide_block_floor(const Params<R>& P, Store<R>& st, Frame& F, const R* uB, const R* wB, R zB) {
     const ContactClass<R>& c = P.cc[CC_BLOCK_FLOOR];
-    R nx = F.nB[0], ny = F.nB[1], nz = F.nB[2], s = P.block_s;
+    R nx = F.nB()[0], ny = F.nB()[1], nz = F.nB()[2], s = P.block_s;
     R low = zB - (abs_(nx) + abs_(ny) + abs_(nz)) * s;
     if (!(low < c.margin)) return;
 #pragma unroll
@@ -518,7 +523,7 @@ template <typename R, bool BLK> struct Sim {
         R wr[3];
         cross_(wB, r, wr);
         R pv[3] = {uB[0] + wr[0], uB[1] + wr[1], uB[2] + wr[2]};
-        R vn = dot_(F.nB, pv), vt1 = dot_(F.t1B, pv), vt2 = dot_(F.t2B, pv);
+        R vn = dot_(F.nB(), pv), vt1 = dot_(F.t1B(), pv), vt2 = -dot_(F.xB(), pv);
         R imp = impedance_(c, d);
         int sl = SLOT_BLOCK + F.nfb;
         st.set(sl, 0, r[0]); st.set(sl, 1, r[1]); st.set(sl, 2, r[2]);
@@ -866,12 +871,12 @@ template <typename R, bool BLK> struct Sim {
         cross_(x + 3, r, t);
         R xs = sel == 1 ? x[6] : (sel == 2 ? x[7] : (R)0);
         R pa[3] = {x[0] + t[0] + xs * wc[0], x[1] + t[1] + xs * wc[1], x[2] + t[2] + xs * wc[2]};
-        int mk = rows_(dot_(F.nT, pa) - An, mu * dot_(F.t1T, pa) - Bt1, mu * dot_(F.t2T, pa) - Bt2, D, cst, l, get4(M.hR, c), sm);
+        int mk = rows_(dot_(F.nT(), pa) - An, mu * dot_(F.t1T(), pa) - Bt1, -mu * dot_(F.xT(), pa) - Bt2, D, cst, l, get4(M.hR, c), sm);
         M.nR |= put4(mk, c);
         if constexpr (FORCES) {
           R fn = D * (l[0] + l[1] + l[2] + l[3]), f1 = D * mu * (l[0] - l[1]), f2 = D * mu * (l[2] - l[3]);
-          R fb[3] = {F.nT[0] * fn + F.t1T[0] * f1 + F.t2T[0] * f2, F.nT[1] * fn + F.t1T[1] * f1 + F.t2T[1] * f2,
-                     F.nT[2] * fn + F.t1T[2] * f1 + F.t2T[2] * f2};
+          R fb[3] = {F.nT()[0] * fn + F.t1T()[0] * f1 - F.xT()[0] * f2, F.nT()[1] * fn + F.t1T()[1] * f1 - F.xT()[1] * f2,
+                     F.nT()[2] * fn + F.t1T()[2] * f1 - F.xT()[2] * f2};
           cross_(r, fb, t);
           fcon[0] += fb[0]; fcon[1] += fb[1]; fcon[2] += fb[2];
           fcon[3] += t[0]; fcon[4] += t[1]; fcon[5] += t[2];
@@ -889,12 +894,12 @@ template <typename R, bool BLK> struct Sim {
           R t[3];
           cross_(x + 11, r, t);
           R pa[3] = {x[8] + t[0], x[9] + t[1], x[10] + t[2]};
-          int mk = rows_(dot_(F.nB, pa) - An, mu * dot_(F.t1B, pa) - Bt1, mu * dot_(F.t2B, pa) - Bt2, D, cst, l, get4(M.hX, c), sm);
+          int mk = rows_(dot_(F.nB(), pa) - An, mu * dot_(F.t1B(), pa) - Bt1, -mu * dot_(F.xB(), pa) - Bt2, D, cst, l, get4(M.hX, c), sm);
           M.nX |= put4(mk, c);
           if constexpr (FORCES) {
             R fn = D * (l[0] + l[1] + l[2] + l[3]), f1 = D * mu * (l[0] - l[1]), f2 = D * mu * (l[2] - l[3]);
-            R fb[3] = {F.nB[0] * fn + F.t1B[0] * f1 + F.t2B[0] * f2, F.nB[1] * fn + F.t1B[1] * f1 + F.t2B[1] * f2,
-                       F.nB[2] * fn + F.t1B[2] * f1 + F.t2B[2] * f2};
+            R fb[3] = {F.nB()[0] * fn + F.t1B()[0] * f1 - F.xB()[0] * f2, F.nB()[1] * fn + F.t1B()[1] * f1 - F.xB()[1] * f2,
+                       F.nB()[2] * fn + F.t1B()[2] * f1 - F.xB()[2] * f2};
             cross_(r, fb, t);
             fcon[8] += fb[0]; fcon[9] += fb[1]; fcon[10] += fb[2];
             fcon[11] += t[0]; fcon[12] += t[1]; fcon[13] += t[2];
@@ -1013,12 +1018,12 @@ template <typename R, bool BLK> struct Sim {
         R mu = sel == 0 ? P.cc[CC_TORSO_FLOOR].mu : P.cc[CC_WHEEL_FLOOR].mu;
         R wc[3], rn[3], r1[3], r2[3];
         wheel_col(P, sel, r, wc);
-        cross_(r, F.nT, rn); cross_(r, F.t1T, r1); cross_(r, F.t2T, r2);
-        R wn = dot_(wc, F.nT), w1 = dot_(wc, F.t1T), w2 = dot_(wc, F.t2T);
+        cross_(r, F.nT(), rn); cross_(r, F.t1T(), r1); cross_(F.xT(), r, r2);  // r x t2 = x_row x r
+        R wn = dot_(wc, F.nT()), w1 = dot_(wc, F.t1T()), w2 = -dot_(wc, F.xT());
         R zL = sel == 1 ? (R)1 : (R)0, zR = sel == 2 ? (R)1 : (R)0;
-        V2<R> gn[4] = {v2_make(F.nT[0], F.nT[1]), v2_make(F.nT[2], rn[0]), v2_make(rn[1], rn[2]), v2_make(zL * wn, zR * wn)};
-        V2<R> g1[4] = {v2_make(F.t1T[0], F.t1T[1]), v2_make(F.t1T[2], r1[0]), v2_make(r1[1], r1[2]), v2_make(zL * w1, zR * w1)};
-        V2<R> g2[4] = {v2_make(F.t2T[0], F.t2T[1]), v2_make(F.t2T[2], r2[0]), v2_make(r2[1], r2[2]), v2_make(zL * w2, zR * w2)};
+        V2<R> gn[4] = {v2_make(F.nT()[0], F.nT()[1]), v2_make(F.nT()[2], rn[0]), v2_make(rn[1], rn[2]), v2_make(zL * wn, zR * wn)};
+        V2<R> g1[4] = {v2_make(F.t1T()[0], F.t1T()[1]), v2_make(F.t1T()[2], r1[0]), v2_make(r1[1], r1[2]), v2_make(zL * w1, zR * w1)};
+        V2<R> g2[4] = {v2_make(-F.xT()[0], -F.xT()[1]), v2_make(-F.xT()[2], r2[0]), v2_make(r2[1], r2[2]), v2_make(zL * w2, zR * w2)};
         int mk = contact_into<0, 4>(H, rhs2, gn, g1, g2, mu, D, An, Bt1, Bt2, ev, get4(srcR, c), x2);
         M.hR |= put4(mk, c);
       }
@@ -1029,10 +1034,10 @@ template <typename R, bool BLK> struct Sim {
           R An = st.get(s, 3), Bt1 = st.get(s, 4), Bt2 = st.get(s, 5), D = st.get(s, 6);
           const bool ev = first && !(BRS_MASK_HINT && c < F.pnfb);
           R rn[3], r1[3], r2[3];
-          cross_(r, F.nB, rn); cross_(r, F.t1B, r1); cross_(r, F.t2B, r2);
-          V2<R> gn[3] = {v2_make(F.nB[0], F.nB[1]), v2_make(F.nB[2], rn[0]), v2_make(rn[1], rn[2])};
-          V2<R> g1[3] = {v2_make(F.t1B[0], F.t1B[1]), v2_make(F.t1B[2], r1[0]), v2_make(r1[1], r1[2])};
-          V2<R> g2[3] = {v2_make(F.t2B[0], F.t2B[1]), v2_make(F.t2B[2], r2[0]), v2_make(r2[1], r2[2])};
+          cross_(r, F.nB(), rn); cross_(r, F.t1B(), r1); cross_(F.xB(), r, r2);
+          V2<R> gn[3] = {v2_make(F.nB()[0], F.nB()[1]), v2_make(F.nB()[2], rn[0]), v2_make(rn[1], rn[2])};
+          V2<R> g1[3] = {v2_make(F.t1B()[0], F.t1B()[1]), v2_make(F.t1B()[2], r1[0]), v2_make(r1[1], r1[2])};
+          V2<R> g2[3] = {v2_make(-F.xB()[0], -F.xB()[1]), v2_make(-F.xB()[2], r2[0]), v2_make(r2[1], r2[2])};
           int mk = contact_into<4, 3>(H, rhs2, gn, g1, g2, P.cc[CC_BLOCK_FLOOR].mu, D, An, Bt1, Bt2, ev, get4(srcX, c), x2);
           M.hX |= put4(mk, c);
         }
@@ -1129,14 +1134,12 @@ template <typename R, bool BLK> struct Sim {
     // kinematics
     R qf[4] = {(R)S.q[0], (R)S.q[1], (R)S.q[2], (R)S.q[3]};
     quat2mat_(qf, F.RT);
-#pragma unroll
-    for (int i = 0; i < 3; i++) { F.nT[i] = F.RT[6 + i]; F.t1T[i] = F.RT[3 + i]; F.t2T[i] = -F.RT[i]; }
     R u[3];
     mulT_(F.RT, S.v, u);
     R zT = (R)(S.p[2] - P.floor_z_d);
     // smooth forces in body coordinates
     R wx = S.w[0], wy = S.w[1], wz = S.w[2];
-    R gb[3] = {-P.g * F.nT[0], -P.g * F.nT[1], -P.g * F.nT[2]};
+    R gb[3] = {-P.g * F.nT()[0], -P.g * F.nT()[1], -P.g * F.nT()[2]};
     f[0] = -P.mcz * wx * wz + P.m * gb[0];
     f[1] = -P.mcz * wy * wz + P.m * gb[1];
     f[2] = P.mcz * (wx * wx + wy * wy) + P.m * gb[2];
@@ -1172,15 +1175,13 @@ template <typename R, bool BLK> struct Sim {
     if constexpr (BLK) {
       R qb[4] = {(R)S.bq[0], (R)S.bq[1], (R)S.bq[2], (R)S.bq[3]};
       quat2mat_(qb, F.RB);
-#pragma unroll
-      for (int i = 0; i < 3; i++) { F.nB[i] = F.RB[6 + i]; F.t1B[i] = F.RB[3 + i]; F.t2B[i] = -F.RB[i]; }
       R uB[3];
       mulT_(F.RB, S.bv, uB);
       R zB = (R)(S.bp[2] - P.floor_z_d);
 #pragma unroll
       for (int i = 0; i < 3; i++) {
         F.dTB[i] = (R)(S.p[i] - S.bp[i]);
-        F.a0[8 + i] = -P.g * F.nB[i];
+        F.a0[8 + i] = -P.g * F.nB()[i];
         F.a0[11 + i] = 0;
       }
       BRS_TIC(2);
@@ -1236,7 +1237,7 @@ template <typename R, bool BLK> struct Sim {
     S.th[1] += P.h_d * (double)S.ww[1];
     if constexpr (BLK) {
       // block smooth force: gravity only (isotropic inertia: no gyroscopic torque)
-      R ab[3], al[3] = {fcon[8] * P.inv_mB - P.g * F.nB[0], fcon[9] * P.inv_mB - P.g * F.nB[1], fcon[10] * P.inv_mB - P.g * F.nB[2]};
+      R ab[3], al[3] = {fcon[8] * P.inv_mB - P.g * F.nB()[0], fcon[9] * P.inv_mB - P.g * F.nB()[1], fcon[10] * P.inv_mB - P.g * F.nB()[2]};
       mul_(F.RB, al, ab);
 #pragma unroll
       for (int i = 0; i < 3; i++) { S.bv[i] += P.h * ab[i]; S.bw[i] += P.h * fcon[11 + i] * P.inv_IB; }
