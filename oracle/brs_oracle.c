@@ -179,6 +179,9 @@ typedef struct {
   double ep_return;
   int bad_count;
   double last_ctrl[2];
+  /* later variants: wheel/floor friction of this episode (Env02, env02_v1.py:57-65), target-speed schedule and pitch
+   * offset (Env01_v3, env01_v3.py:16-53) */
+  double muw, dts, poff, tws;
   double* script;
   int script_n, script_pos;
   int stub;
@@ -571,13 +574,15 @@ static void box_cyl_own(const model_t* m, const double* wpos, const double* waxi
   if (found) add_contact(con, n, best, bpos_c, bn, wbody, B_BLOCK, cp);
 }
 
-static int collide(const model_t* m, const kin_t* k, bo_contact* con) {
+static int collide(const model_t* m, const kin_t* k, bo_contact* con, double muw) {
   int n = 0;
+  cparam cpw = m->cp_wheel_floor;
+  if (muw > 0) cpw.mu = muw; /* max(floor, wheel) friction, both set to the episode's value */
   double gpos[3], t[3], gmat[9];
   /* floor <-> wheels (Env01: explicit <pair>, envs/env01_v1.xml:30-33; Env03: geom defaults) */
   for (int w = 0; w < 2; w++) {
     mulMat3(gmat, k->xmat[B_LW + w], m->wheel_gmat);
-    plane_cylinder(m, k->xpos[B_LW + w], gmat, B_LW + w, &m->cp_wheel_floor, con, &n);
+    plane_cylinder(m, k->xpos[B_LW + w], gmat, B_LW + w, &cpw, con, &n);
   }
   /* floor <-> torso box (dynamic pair, geom defaults) */
   mulMatVec3(t, k->xmat[B_TORSO], m->torso_gpos);
@@ -836,12 +841,12 @@ static void solve_newton(const model_t* m, fwd_t* f, const double* warm) {
 }
 
 static void forward(const model_t* m, const double* qpos, const double* qvel, const double* ctrl, const double* warm,
-                    fwd_t* f) {
+                    fwd_t* f, double muw) {
   int nv = m->nv;
   kinematics(m, qpos, &f->k);
   mass_matrix(m, &f->k, f->M);
   chol(f->M, nv, NVMAX, f->LM);
-  f->ncon = collide(m, &f->k, f->con);
+  f->ncon = collide(m, &f->k, f->con, muw);
   make_constraints(m, qvel, f);
   for (int j = 0; j < nv; j++) f->passive[j] = f->actuator[j] = 0;
   for (int w = 0; w < 2; w++) f->passive[6 + w] = -m->damping * qvel[6 + w]; /* envs/robot-02.xml:11,16 */
@@ -876,7 +881,7 @@ static int bad_number(double x) { return !(x == x) || x > 1e10 || x < -1e10; }
 /* one mj_step: forward at (qpos,qvel) then semi-implicit advance; returns 0, or 1 if the state went bad */
 static int substep(const model_t* m, env_t* e, const double* ctrl, fwd_t* f) {
   int nv = m->nv;
-  forward(m, e->qpos, e->qvel, ctrl, e->warm, f);
+  forward(m, e->qpos, e->qvel, ctrl, e->warm, f, m->variant == BO_ENV02_V1 ? e->muw : 0.0);
   memcpy(e->warm, f->qacc, nv * sizeof(double));
   /* accessor pose = kinematics of THIS forward pass (lags the advanced qpos by one substep) */
   memcpy(e->xquat, f->k.tquat, sizeof e->xquat);
@@ -905,7 +910,7 @@ static int substep(const model_t* m, env_t* e, const double* ctrl, fwd_t* f) {
 static void model_init(model_t* m, int variant, uint32_t flags, int max_episode_steps, int substeps, double timestep) {
   memset(m, 0, sizeof *m);
   m->variant = variant;
-  m->family = (variant == BO_ENV01_V1 || variant == BO_ENV01_V2) ? 1 : 3;
+  m->family = (variant == BO_ENV03_V1 || variant == BO_ENV03_V2) ? 3 : 1;
   m->has_block = m->family == 3;
   m->nq = m->has_block ? 16 : 9;
   m->nv = m->has_block ? 14 : 8;
@@ -951,7 +956,7 @@ static void model_init(model_t* m, int variant, uint32_t flags, int max_episode_
   cparam def;
   def.mu = 1.0; def.solref[0] = 0.02; def.solref[1] = 1.0; set_default_solimp(def.solimp); def.margin = 0;
   m->cp_torso_floor = def;
-  if (m->family == 1) { /* explicit pairs, envs/env01_v1.xml:30-33 */
+  if (m->family == 1 && variant != BO_ENV02_V1) { /* explicit pairs, envs/env01_v1.xml:30-33 (Env02's scene has none: envs/env02_v1.xml) */
     cparam p = def;
     p.mu = 0.9; p.solref[0] = 0.02; p.solref[1] = 0.5;
     p.solimp[0] = 0.5; p.solimp[1] = 0.5; p.solimp[2] = 0.002; p.solimp[3] = 0.5; p.solimp[4] = 2;
@@ -1032,10 +1037,27 @@ static double get_pitch(const model_t* m, env_t* e, stream_t* s) {
   double p, y;
   bo_pitch_yaw(e->xquat, &p, &y);
   if (m->noise) p += (snext(s) - 0.5) * 0.05;
+  if (m->variant == BO_ENV01_V3) p += e->poff; /* env01_v3.py:23-25 */
   return p;
 }
 /* RobotBaseEnv.py:190-219 */
+/* env01_v3.py:55-96 */
+static double get_reward_v3(const model_t* m, env_t* e, stream_t* s) {
+  double reward = 0.6, pitch = get_pitch(m, e, s);
+  double ws = (e->qvel[6] + (-1 * e->qvel[7])) / 2, dv = e->tws - ws;
+  reward -= fabs(pitch) * 0.05;
+  double mdv = dv > 40.0 ? 40.0 : (dv < -40.0 ? -40.0 : dv), dv_s = fabs(mdv / 40.0);
+  reward -= 0.15 * dv_s;
+  if (e->tws > 0 && e->tws > ws) reward += (-1.0 * pitch) * 10.0 * dv_s;
+  else if (e->tws < 0 && e->tws < ws) reward += (1.0 * pitch) * 10.0 * dv_s;
+  else if (e->tws > 0 && e->tws < ws) reward += (1.0 * pitch) * 10.0 * dv_s;
+  else if (e->tws < 0 && e->tws > ws) reward += (-1.0 * pitch) * 10.0 * dv_s;
+  double dyd = 0 - (e->qvel[6] - (-1 * e->qvel[7]));
+  reward -= 0.007 * fabs(dyd);
+  return reward;
+}
 static double get_reward(const model_t* m, env_t* e, stream_t* s) {
+  if (m->variant == BO_ENV01_V3) return get_reward_v3(m, e, s);
   double reward = 1.0, vel_l = e->qvel[6], vel_r = e->qvel[7];
   double dv = 0 - (vel_l * -1 + vel_r) / 2.0;
   double dyd = 0 - e->qvel[5];
@@ -1060,7 +1082,7 @@ static void get_obs(const model_t* m, env_t* e, stream_t* s, int at_reset, float
   obs[1] = (float)(pitch_dot / 1);
   obs[2] = (float)(vl / 170.0 * 4);
   obs[3] = (float)(vr / 170.0 * 4);
-  obs[4] = (float)((0.0 - wheel_speed) / 170.0 * 4);
+  obs[4] = (float)(((m->variant == BO_ENV01_V3 ? e->tws : 0.0) - wheel_speed) / 170.0 * 4);
   obs[5] = (float)((0.0 - wheel_yaw) / 45.0 * 3);
 }
 /* scipy from_euler('xyz',[a,b,c]).as_quat() = (x,y,z,w) of Rz(c)Ry(b)Rx(a), stored into MuJoCo's (w,x,y,z)
@@ -1101,12 +1123,19 @@ static void env_reset(const bo_handle* h, int idx, float* obs) {
   memset(e->qpos, 0, sizeof e->qpos); memset(e->qvel, 0, sizeof e->qvel); memset(e->warm, 0, sizeof e->warm);
   e->time = 0; e->elapsed = 0; e->ep_return = 0;
   /* reset_model (env01_v2.py:52-71): qpos0 + U(-0.01,0.01)^nq from the seeded generator, qpos[2] = 0 */
+  if (m->variant == BO_ENV01_V3) { /* env01_v3.py:40-53: two draws of the seeded generator BEFORE Env01.reset_model */
+    e->tws = 0;
+    e->dts = -10.0 + 20.0 * snext(&s);
+    if (e->dts > 0) e->dts += 10; else e->dts -= 10;
+    e->poff = -0.0349066 + 2 * 0.0349066 * snext(&s);
+  }
   double q0[NQMAX] = {0};
   q0[3] = 1; q0[12] = 1;
   for (int i = 0; i < m->nq; i++) e->qpos[i] = q0[i] + (-0.01 + 0.02 * snext(&s));
   e->qpos[2] = 0;
   double xr = (snext(&s) - 0.5) * 2 * PI, yr = (snext(&s) - 0.5) * m->Sy, zr = (snext(&s) - 0.5) * m->Sz;
   bo_euler_slot_quat(xr, yr, zr, e->qpos + 3);
+  if (m->variant == BO_ENV02_V1) e->muw = snext(&s) / 2 + 0.5; /* env02_v1.py:61-65, after the pose draws */
   /* set_state -> mj_forward: accessor pose is current */
   memcpy(e->xquat, e->qpos + 3, sizeof e->xquat);
   normalize4(e->xquat);
@@ -1121,6 +1150,12 @@ static void env_step(bo_handle* h, int idx, const float* action, float* obs, flo
   env_t* e = h->e + idx;
   stream_t s;
   stream_open(&s, h, e, idx);
+  if (m->variant == BO_ENV01_V3) { /* env01_v3.py:28-36: schedule keyed on data.time at the start of step */
+    if (e->time > 5.5) e->tws = 3.0 * e->dts;
+    else if (e->time > 4.5) e->tws = 2.0 * e->dts;
+    else if (e->time > 3.0) e->tws = -1.0 * e->dts;
+    else if (e->time > 1.0) e->tws = e->dts;
+  }
   double rew = get_reward(m, e, &s); /* on the PRE-step state (env01_v2.py:29) */
   double ctrl[2] = {e->qvel[6] + (double)action[0] * 4.0, e->qvel[7] + (double)action[1] * 4.0}; /* :31-36 */
   e->last_ctrl[0] = ctrl[0]; e->last_ctrl[1] = ctrl[1];
@@ -1167,7 +1202,7 @@ static void env_step(bo_handle* h, int idx, const float* action, float* obs, flo
  * ========================================================================================== */
 bo_handle* bo_create(int variant, int n, uint64_t seed, int64_t gid_base, uint32_t flags, int max_episode_steps,
                      int substeps, double timestep) {
-  if (variant < 0 || variant > 3 || n <= 0) return NULL;
+  if (variant < 0 || variant > 5 || n <= 0) return NULL;
   bo_handle* h = (bo_handle*)calloc(1, sizeof *h);
   model_init(&h->m, variant, flags, max_episode_steps, substeps, timestep);
   h->n = n; h->seed = seed; h->gid_base = gid_base; h->nthreads = 1;
@@ -1179,6 +1214,7 @@ bo_handle* bo_create(int variant, int n, uint64_t seed, int64_t gid_base, uint32
     e->rng_ctr = 1;
     e->qpos[3] = 1; e->qpos[12] = 1; e->xquat[0] = 1;
     e->block_timer = NAN; e->last_pitch = 0;
+    e->muw = 1.0; /* geom default until the first reset */
   }
   return h;
 }
@@ -1253,8 +1289,9 @@ void bo_get_aux(const bo_handle* h, double* aux) {
     const env_t* e = h->e + i;
     double p, y;
     bo_pitch_yaw(e->xquat, &p, &y);
-    double* a = aux + 10 * (size_t)i;
+    double* a = aux + 14 * (size_t)i;
     a[8] = e->last_ctrl[0]; a[9] = e->last_ctrl[1];
+    a[10] = e->muw; a[11] = e->dts; a[12] = e->poff; a[13] = e->tws;
     a[0] = e->last_pitch; a[1] = e->block_timer; a[2] = e->elapsed; a[3] = e->rng_ctr; a[4] = e->side_front;
     a[5] = p; a[6] = e->ep_return; a[7] = e->bad_count;
   }
@@ -1262,9 +1299,10 @@ void bo_get_aux(const bo_handle* h, double* aux) {
 void bo_set_aux(bo_handle* h, const double* aux) {
   for (int i = 0; i < h->n; i++) {
     env_t* e = h->e + i;
-    const double* a = aux + 10 * (size_t)i;
+    const double* a = aux + 14 * (size_t)i;
     e->last_pitch = a[0]; e->block_timer = a[1]; e->elapsed = (int)a[2]; e->rng_ctr = (uint32_t)a[3];
     e->side_front = a[4] != 0; e->ep_return = a[6];
+    e->muw = a[10]; e->dts = a[11]; e->poff = a[12]; e->tws = a[13];
   }
 }
 void bo_get_xpose(const bo_handle* h, double* xquat, double* xpos) {
@@ -1284,7 +1322,7 @@ void bo_forward(bo_handle* h, int idx, const double ctrl[2], bo_forward_out* o) 
   const model_t* m = &h->m;
   env_t* e = h->e + idx;
   fwd_t* f = (fwd_t*)malloc(sizeof *f);
-  forward(m, e->qpos, e->qvel, ctrl, e->warm, f);
+  forward(m, e->qpos, e->qvel, ctrl, e->warm, f, m->variant == BO_ENV02_V1 ? e->muw : 0.0);
   memset(o, 0, sizeof *o);
   o->nv = m->nv; o->ncon = f->ncon; o->nefc = f->nefc; o->solver_iter = f->solver_iter;
   memcpy(o->M, f->M, sizeof o->M);

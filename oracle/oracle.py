@@ -13,7 +13,8 @@ _DIR = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_DIR, "libbrs_oracle.so")
 
 ENV01_V1, ENV01_V2, ENV03_V1, ENV03_V2 = 0, 1, 2, 3
-VARIANTS = {"Env01-v1": 0, "Env01-v2": 1, "Env03-v1": 2, "Env03-v2": 3}
+VARIANTS = {"Env01-v1": 0, "Env01-v2": 1, "Env03-v1": 2, "Env03-v2": 3, "Env01-v3": 4, "Env02-v1": 5}
+AUX_COLS = 14
 FLAG_AUTO_RESET, FLAG_NOISE_ON, FLAG_NOISE_OFF = 1, 2, 4
 MAXNV, MAXCON = 14, 40
 
@@ -185,7 +186,7 @@ class Oracle:
         self.L.bo_set_state(self.h, _dp(qpos), _dp(qvel), _dp(warm), _dp(time))
 
     def get_aux(self):
-        aux = np.zeros((self.n, 10))
+        aux = np.zeros((self.n, AUX_COLS))
         self.L.bo_get_aux(self.h, _dp(aux))
         return aux
 

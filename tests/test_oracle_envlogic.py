@@ -158,3 +158,69 @@ def test_philox_kat():
     assert O.philox([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
     assert O.philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
         [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+CLS2VARIANT_F3 = {"Env02": "Env02-v1", "Env01_v3": "Env01-v3"}
+
+
+def _reset_script_f3(rec, key_r, key_s):
+    r = rec[key_r]
+    pre = []
+    if rec["cls"] == "Env01_v3":  # two scalar draws of the seeded generator come first (env01_v3.py:44-52)
+        a, b = rec[key_s]
+        pre = [(a + 10.0) / 20.0, (b + 0.0349066) / (2 * 0.0349066)]
+    return np.concatenate([pre, (np.array(r["gym_uniform"]) + 0.01) / 0.02, np.array(r["uniforms"])])
+
+
+@pytest.mark.parametrize("idx", range(7))
+def test_sequences_f3(golden, idx):
+    """Env02-v1 (per-episode friction) and Env01-v3 (target-speed schedule, pitch offset, shaped reward): SURVEY §8 f3"""
+    rec = golden["sequences_f3"][idx]
+    o = O.Oracle(CLS2VARIANT_F3[rec["cls"]], 1, seed=5)
+    r = rec["reset"]
+    o.script_uniforms(0, _reset_script_f3(rec, "reset", "reset_gym_scalars"))
+    obs = o.reset()
+    assert o.script_remaining(0) == 0
+    qpos, qvel, _, _ = o.get_state()
+    np.testing.assert_allclose(qpos[0], r["qpos"], atol=1e-12)
+    np.testing.assert_allclose(obs[0], np.array(r["obs"], np.float32), rtol=1e-6, atol=1e-7)
+    aux = o.get_aux()
+    ex = r["extras"]
+    if rec["cls"] == "Env02":
+        assert abs(aux[0, 10] - ex["friction"]) < 1e-12 and ex["friction"] == ex["floor_friction"]
+    else:
+        np.testing.assert_allclose(aux[0, 11:14], [ex["delay_target_speed"], ex["pitch_offset"], ex["target_wheel_speed"]], atol=1e-9)
+    o.set_state(time=np.array([rec["time0"]]))
+    for k, st in enumerate(rec["steps"]):
+        o.stub_physics(0, st["post"]["qpos"], st["post"]["qvel"], st["post"]["xquat"], st["post"]["xpos"])
+        o.script_uniforms(0, st["uniforms"])
+        obs, rew, term, trunc, _ = o.step(np.array([st["action"]], np.float32))
+        assert o.script_remaining(0) == 0
+        ref = np.array(st["obs"], np.float32)
+        cols = [0, 2, 3, 4, 5] if (k == 0 and rec["time0"] > 0) else [0, 1, 2, 3, 4, 5]  # (time0 hack: dt of the first finite difference)
+        np.testing.assert_allclose(obs[0, cols], ref[cols], rtol=2e-6, atol=1e-6, err_msg=f"step {k}")
+        assert abs(rew[0] - st["reward"]) < 1e-6 * max(1.0, abs(st["reward"])), (k, rew[0], st["reward"])
+        assert bool(term[0]) == st["terminated"]
+        aux = o.get_aux()
+        np.testing.assert_allclose(aux[0, 8:10], st["ctrl"], rtol=1e-12, atol=1e-12)
+        assert abs(aux[0, 13] - st["extras"]["target_wheel_speed"]) < 1e-9, k
+    o.script_uniforms(0, _reset_script_f3(rec, "reset2", "reset2_gym_scalars"))
+    obs = o.reset()
+    np.testing.assert_allclose(obs[0], np.array(rec["reset2"]["obs"], np.float32), rtol=1e-6, atol=1e-7)
+    aux = o.get_aux()
+    ex = rec["reset2"]["extras"]
+    if rec["cls"] == "Env02":
+        assert abs(aux[0, 10] - ex["friction"]) < 1e-12
+    else:
+        np.testing.assert_allclose(aux[0, 11:14], [ex["delay_target_speed"], ex["pitch_offset"], 0.0], atol=1e-9)
+
+
+def test_env02_friction_enters_the_contact_model():
+    """lower friction => smaller tangential force capacity: the wheel pyramid rows use the episode's mu"""
+    o = O.Oracle("Env02-v1", 1, seed=1)
+    o.reset()
+    aux = o.get_aux(); aux[0, 10] = 0.5; o.set_aux(aux)
+    q = np.array([[0, 0, -0.0203, 1, 0, 0, 0, 0, 0.0]]); v = np.zeros((1, 8)); v[0, 1] = 0.3
+    o.set_state(q, v)
+    f = o.forward()
+    assert f["ncon"] == 4 and all(abs(c["mu"] - 0.5) < 1e-12 for c in f["contacts"])

@@ -163,7 +163,8 @@ class FakeData:
 def _attach(env, nq, nv, gym_seed):
     """give a stub-constructed env the attributes MujocoEnv would have made"""
     env.data = FakeData(nq, nv)
-    env.model = _View(nq=nq, nv=nv)
+    geoms = {n: _View(friction=np.array([1.0, 0.005, 0.0001])) for n in ('floor', 'l_wheel_geom', 'r_wheel_geom')}
+    env.model = _View(nq=nq, nv=nv, geom=lambda name: geoms[name], _geoms=geoms)
     q0 = np.zeros(nq)
     q0[3] = 1.0
     if nq == 16:
@@ -216,6 +217,13 @@ def L(x):
     return [float(v) for v in np.asarray(x, dtype=np.float64).ravel()]
 
 
+def _extras(e):
+    """per-env scalars of the later variants: wheel/floor friction (Env02), target speed schedule + pitch offset (Env01_v3)"""
+    return dict(friction=float(e.model._geoms['l_wheel_geom'].friction[0]), floor_friction=float(e.model._geoms['floor'].friction[0]),
+                delay_target_speed=float(getattr(e, 'delay_target_speed', 0.0)), pitch_offset=float(getattr(e, 'pitch_offset', 0.0)),
+                target_wheel_speed=float(e.target_wheel_speed))
+
+
 # --------------------------------------------------------------------------------------
 def main():
     registry = _install_stubs()
@@ -225,6 +233,8 @@ def main():
     from balance_robot.envs.env01_v2 import Env01_v2
     from balance_robot.envs.env03_v1 import Env03
     from balance_robot.envs.env03_v2 import Env03_v2
+    from balance_robot.envs.env01_v3 import Env01_v3
+    from balance_robot.envs.env02_v1 import Env02
     from balance_robot.envs import RobotBaseEnv as rb
 
     out = {"_about": "generated by tools/gen_golden.py from the reference's env classes with physics stubbed; data only"}
@@ -256,7 +266,7 @@ def main():
     out["reward"] = cases
 
     # ---------------------------------------------------------------- (3) scripted step sequences
-    def run_steps(cls, nq, nv, np_seed, nsteps, block=False, act_scale=1.0, slow_block_at=()):
+    def run_steps(cls, nq, nv, np_seed, nsteps, block=False, act_scale=1.0, slow_block_at=(), time0=0.0):
         np.random.seed(np_seed)
         with _UniformLog() as ctor_log:
             e = _attach(cls(), nq, nv, np_seed + 1000)
@@ -265,14 +275,20 @@ def main():
             rec["attack_side_front"] = bool(getattr(e, "attack_side_front", False))
             rec["block_delay"] = float(e.block_delay)
         # reset through the reference's reset_model (gym RNG draws are recorded separately)
+        pre = []
+        if cls.__name__ == "Env01_v3":  # reset_model draws two scalars from the seeded generator first
+            pre = [float(e.np_random.uniform(low=-10.0, high=10)), float(e.np_random.uniform(low=-0.0349066, high=0.0349066))]
         gym_draw = e.np_random.uniform(size=nq, low=-0.01, high=0.01)
         e.np_random = np.random.default_rng(np_seed + 1000)  # rewind so reset_model draws the same
+        rec["reset_gym_scalars"] = pre
         with _UniformLog() as log:
             obs0 = e.reset_model()
         rec["reset"] = dict(gym_uniform=L(gym_draw), uniforms=list(log.draws), qpos=L(e.data.qpos),
                             qvel=L(e.data.qvel), xquat=L(e.data.xquat_robot), xpos=L(e.data.xpos_robot),
-                            obs=L(obs0), time=float(e.data.time),
+                            obs=L(obs0), time=float(e.data.time), extras=_extras(e),
                             block_timer=None if not block else e.block_delay_time_start)
+        e.data.time = time0  # (Env01_v3's schedule keys on data.time at the start of step)
+        rec["time0"] = time0
         steps = []
         srng = np.random.default_rng(np_seed + 7)
         for k in range(nsteps):
@@ -308,18 +324,23 @@ def main():
                               ctrl=[float(e.data.actuator("motor_l_wheel").ctrl[0]),
                                     float(e.data.actuator("motor_r_wheel").ctrl[0])],
                               obs=L(ob), reward=float(rew), terminated=bool(term), truncated=bool(trunc),
-                              time=float(e.data.time),
+                              time=float(e.data.time), extras=_extras(e),
                               qpos_after=L(e.data.qpos), qvel_after=L(e.data.qvel),
                               block_timer=None if not block else e.block_delay_time_start))
         rec["steps"] = steps
         # a second reset in the middle of an episode: last_time/last_pitch are NOT cleared
         e.np_random = np.random.default_rng(np_seed + 2000)
-        gym_draw = np.random.default_rng(np_seed + 2000).uniform(size=nq, low=-0.01, high=0.01)
+        g2 = np.random.default_rng(np_seed + 2000)
+        pre2 = []
+        if cls.__name__ == "Env01_v3":
+            pre2 = [float(g2.uniform(low=-10.0, high=10)), float(g2.uniform(low=-0.0349066, high=0.0349066))]
+        gym_draw = g2.uniform(size=nq, low=-0.01, high=0.01)
+        rec["reset2_gym_scalars"] = pre2
         e.data.time = 0.0  # what mj_resetData does
         with _UniformLog() as log:
             obs1 = e.reset_model()
         rec["reset2"] = dict(gym_uniform=L(gym_draw), uniforms=list(log.draws), qpos=L(e.data.qpos),
-                             qvel=L(e.data.qvel), xquat=L(e.data.xquat_robot), obs=L(obs1))
+                             qvel=L(e.data.qvel), xquat=L(e.data.xquat_robot), obs=L(obs1), extras=_extras(e))
         return rec
 
     seqs = []
@@ -330,6 +351,14 @@ def main():
     for s in (15, 16, 17, 18):
         seqs.append(run_steps(Env03_v2, 16, 14, s, 14, block=True, slow_block_at=(2, 5)))
     out["sequences"] = seqs
+    import contextlib, io
+    seqs2 = []
+    with contextlib.redirect_stdout(io.StringIO()):  # the two classes print() on reset
+        seqs2.append(run_steps(Env02, 9, 8, 21, 10))
+        seqs2.append(run_steps(Env02, 9, 8, 22, 10, act_scale=2.0))
+        for sd, t0 in ((23, 0.0), (24, 0.99), (25, 2.98), (26, 4.48), (27, 5.48)):
+            seqs2.append(run_steps(Env01_v3, 9, 8, sd, 10, time0=t0))
+    out["sequences_f3"] = seqs2
 
     # ---------------------------------------------------------------- (4) Env03-v2 block timer over many steps
     # time accumulates 250 x 2e-5 per step in fp64 exactly as MuJoCo does; the `> block_delay`
