@@ -237,6 +237,8 @@ template <typename R, bool BLK> struct EnvState {
   int side_front;
   R ep_return;
   int bad;
+  R muw;            // Env02: wheel/floor friction of this episode (envs/env02_v1.py:57-65)
+  R dts, poff, tws; // Env01-v3: delay_target_speed, pitch_offset, target_wheel_speed (envs/env01_v3.py:16-53)
   int pnfr, pnfb, pnc;  // previous substep: contact-list lengths, body selectors and final active-row masks -- the first
   uint32_t psels, pmR, pmX;  // guess of this substep's active set (not persisted across launches)
 };
@@ -419,6 +421,7 @@ template <typename R, bool BLK> struct Sim {
     int nfr, nfb, nc;  // robot-floor, block-floor, coupled contact counts of this lane
     int pnfr, pnfb, pnc;  // the same of the previous substep
     uint32_t sels, psels, pmR, pmX;
+    R muW, cDW;        // wheel<->floor friction and pyramid regulariser factor of this env
   };
 
   // wheel hinge column for a contact at r (torso frame) on wheel sel (1 L: axis -x at (-px,0,pz); 2 R: +x at (+px,0,pz))
@@ -432,6 +435,7 @@ template <typename R, bool BLK> struct Sim {
                                      int sel, int cls, const R* pt, R dist) {
     if (F.nfr >= N_ROBOT_SLOTS) return;
     const ContactClass<R>& c = P.cc[cls];
+    const R cmu = cls == CC_WHEEL_FLOOR ? F.muW : c.mu, ccD = cls == CC_WHEEL_FLOOR ? F.cDW : c.cD;
     R r[3] = {pt[0] - F.nT()[0] * dist * (R)0.5, pt[1] - F.nT()[1] * dist * (R)0.5, pt[2] - F.nT()[2] * dist * (R)0.5};
     // point velocity in the torso frame
     R wc[3], wr[3];
@@ -444,9 +448,9 @@ template <typename R, bool BLK> struct Sim {
     int s = SLOT_ROBOT + F.nfr;
     st.set(s, 0, r[0]); st.set(s, 1, r[1]); st.set(s, 2, r[2]);
     st.set(s, 3, -c.B * vn - c.K * imp * (dist - c.margin));
-    st.set(s, 4, -c.B * c.mu * vt1);
-    st.set(s, 5, -c.B * c.mu * vt2);
-    st.set(s, 6, imp * rcp_((1 - imp) * c.cD));
+    st.set(s, 4, -c.B * cmu * vt1);
+    st.set(s, 5, -c.B * cmu * vt2);
+    st.set(s, 6, imp * rcp_((1 - imp) * ccD));
     F.sels |= (uint32_t)sel << (2 * F.nfr);
     F.nfr++;
   }
@@ -865,7 +869,7 @@ template <typename R, bool BLK> struct Sim {
         R r[3] = {st.get(s, 0), st.get(s, 1), st.get(s, 2)};
         R An = st.get(s, 3), Bt1 = st.get(s, 4), Bt2 = st.get(s, 5), D = st.get(s, 6);
         int sel = sel_robot(F.sels, c);
-        R mu = sel == 0 ? P.cc[CC_TORSO_FLOOR].mu : P.cc[CC_WHEEL_FLOOR].mu;
+        R mu = sel == 0 ? P.cc[CC_TORSO_FLOOR].mu : F.muW;
         R wc[3], t[3];
         wheel_col(P, sel, r, wc);
         cross_(x + 3, r, t);
@@ -1015,7 +1019,7 @@ template <typename R, bool BLK> struct Sim {
         R An = st.get(s, 3), Bt1 = st.get(s, 4), Bt2 = st.get(s, 5), D = st.get(s, 6);
         int sel = sel_robot(F.sels, c);
         const bool ev = first && !(BRS_MASK_HINT && c < F.pnfr && sel_robot(F.psels, c) == sel);
-        R mu = sel == 0 ? P.cc[CC_TORSO_FLOOR].mu : P.cc[CC_WHEEL_FLOOR].mu;
+        R mu = sel == 0 ? P.cc[CC_TORSO_FLOOR].mu : F.muW;
         R wc[3], rn[3], r1[3], r2[3];
         wheel_col(P, sel, r, wc);
         cross_(r, F.nT(), rn); cross_(r, F.t1T(), r1); cross_(F.xT(), r, r2);  // r x t2 = x_row x r
@@ -1166,6 +1170,8 @@ template <typename R, bool BLK> struct Sim {
     F.nfr = 0; F.nfb = 0; F.nc = 0;
     F.pnfr = S.pnfr; F.pnfb = S.pnfb; F.pnc = S.pnc;
     F.sels = 0; F.psels = S.psels; F.pmR = S.pmR; F.pmX = S.pmX;
+    F.muW = P.per_env_mu ? S.muw : P.cc[CC_WHEEL_FLOOR].mu;
+    F.cDW = P.per_env_mu ? 2 * S.muw * S.muw * (1 + S.muw * S.muw) * P.tran_wheel : P.cc[CC_WHEEL_FLOOR].cD;
     collide_wheel(P, st, F, u, S.w, S.ww, zT, 1, false);
     collide_wheel(P, st, F, u, S.w, S.ww, zT, 2, false);
     collide_torso(P, st, F, u, S.w, S.ww, zT);
@@ -1276,9 +1282,22 @@ template <typename R, bool BLK> struct Sim {
     R p, y;
     pitch_yaw(S.xq, p, y);
     if (P.noise) p += (rng.next() - (R)0.5) * (R)0.05;
+    if (P.v3) p += S.poff;  // envs/env01_v3.py:23-25
     return p;
   }
+  // envs/env01_v3.py:55-96
+  static BRS_HD R get_reward_v3(const Params<R>& P, const ES& S, Stream<R>& rng) {
+    R pitch = get_pitch(P, S, rng);
+    R ws = (S.ww[0] - S.ww[1]) / (R)2, dv = S.tws - ws;
+    R dv_s = abs_(min_(max_(dv, (R)-40), (R)40) / (R)40);
+    R reward = (R)0.6 - abs_(pitch) * (R)0.05 - (R)0.15 * dv_s;
+    R lean = (S.tws > 0 && S.tws > ws) ? (R)-1 : ((S.tws < 0 && S.tws < ws) ? (R)1 : ((S.tws > 0 && S.tws < ws) ? (R)1 : ((S.tws < 0 && S.tws > ws) ? (R)-1 : (R)0)));
+    reward += lean * pitch * (R)10 * dv_s;
+    reward -= (R)0.007 * abs_((R)0 - (S.ww[0] + S.ww[1]));
+    return reward;
+  }
   static BRS_HD R get_reward(const Params<R>& P, const ES& S, Stream<R>& rng) {
+    if (P.v3) return get_reward_v3(P, S, rng);
     R dv = (R)0 - (S.ww[0] * (R)-1 + S.ww[1]) / (R)2;
     R dyd = (R)0 - S.w[2];
     R pitch = get_pitch(P, S, rng);
@@ -1296,7 +1315,7 @@ template <typename R, bool BLK> struct Sim {
     obs[1] = (float)pitch_dot;
     obs[2] = (float)(vl / (R)170 * (R)4);
     obs[3] = (float)(vr / (R)170 * (R)4);
-    obs[4] = (float)(((R)0 - wheel_speed) / (R)170 * (R)4);
+    obs[4] = (float)(((P.v3 ? S.tws : (R)0) - wheel_speed) / (R)170 * (R)4);
     obs[5] = (float)(((R)0 - wheel_yaw) / (R)45 * (R)3);
   }
   // scipy from_euler('xyz',[a,b,c]).as_quat() (x,y,z,w) written unchanged into MuJoCo's (w,x,y,z) slot
@@ -1334,6 +1353,12 @@ template <typename R, bool BLK> struct Sim {
   }
   static BRS_HD void env_reset(const Params<R>& P, ES& S, Stream<R>& rng, float* obs) {
     const R TWO_PI = (R)6.283185307179586476925;
+    if (P.v3) {  // envs/env01_v3.py:40-53: two draws of the seeded generator BEFORE Env01.reset_model
+      S.tws = 0;
+      R d = (R)-10 + (R)20 * rng.next();
+      S.dts = d > 0 ? d + (R)10 : d - (R)10;
+      S.poff = (R)-0.0349066 + (R)(2 * 0.0349066) * rng.next();
+    }
     // MujocoEnv.reset -> mj_resetData ; reset_model: qpos0 + U(-0.01,0.01)^nq, qpos[2] = 0
     R n[16];
 #pragma unroll
@@ -1348,6 +1373,7 @@ template <typename R, bool BLK> struct Sim {
     S.time = 0; S.elapsed = 0; S.ep_return = 0;
     R xr = (rng.next() - (R)0.5) * TWO_PI, yr = (rng.next() - (R)0.5) * P.Sy, zr = (rng.next() - (R)0.5) * P.Sz;
     euler_slot_quat(xr, yr, zr, S.q);
+    if (P.per_env_mu) S.muw = rng.next() / (R)2 + (R)0.5;  // envs/env02_v1.py:61-65, after the pose draws
 #pragma unroll
     for (int i = 0; i < 4; i++) S.xq[i] = S.q[i];
 #pragma unroll
@@ -1362,7 +1388,14 @@ template <typename R, bool BLK> struct Sim {
   }
 
   // ---- one full env step = env_pre (reward + control law on the PRE-step state) -> nsub substeps -> env_post
-  static BRS_HD R env_pre(const Params<R>& P, const ES& S, Stream<R>& rng, float a0, float a1, R& ctrlL, R& ctrlR) {
+  static BRS_HD R env_pre(const Params<R>& P, ES& S, Stream<R>& rng, float a0, float a1, R& ctrlL, R& ctrlR) {
+    if (P.v3) {  // envs/env01_v3.py:28-36: schedule keyed on data.time at the start of step
+      const double t = S.time;  // fp64 like the reference: the accumulated time sits within rounding of the thresholds
+      if (t > 5.5) S.tws = (R)3 * S.dts;
+      else if (t > 4.5) S.tws = (R)2 * S.dts;
+      else if (t > 3.0) S.tws = -S.dts;
+      else if (t > 1.0) S.tws = S.dts;
+    }
     R rew = get_reward(P, S, rng);
     ctrlL = S.ww[0] + (R)a0 * (R)4;  // envs/env01_v2.py:31-36 ; the env does not clip the action
     ctrlR = S.ww[1] + (R)a1 * (R)4;

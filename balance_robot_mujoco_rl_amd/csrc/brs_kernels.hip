@@ -168,8 +168,8 @@ int download_state(brs_handle* h, std::vector<double>& d, std::vector<float>& f,
 extern "C" {
 
 int brs_sizes(int32_t variant, int32_t* nq, int32_t* nv, int32_t* nobs, int32_t* nact) {
-  if (variant < 0 || variant > 3) return BRS_ERR_ARG;
-  bool blk = variant >= 2;
+  if (variant < 0 || variant > 5) return BRS_ERR_ARG;
+  bool blk = variant == 2 || variant == 3;
   if (nq) *nq = blk ? 16 : 9;
   if (nv) *nv = blk ? 14 : 8;
   if (nobs) *nobs = 6;
@@ -180,7 +180,7 @@ int brs_sizes(int32_t variant, int32_t* nq, int32_t* nv, int32_t* nobs, int32_t*
 int brs_create(const brs_config* cfg, brs_handle** out) {
   if (!cfg || !out) return fail(nullptr, BRS_ERR_ARG, "brs_create: null argument");
   *out = nullptr;
-  if (cfg->variant < 0 || cfg->variant > 3) return fail(nullptr, BRS_ERR_ARG, "brs_create: unknown variant");
+  if (cfg->variant < 0 || cfg->variant > 5) return fail(nullptr, BRS_ERR_ARG, "brs_create: unknown variant");
   if (cfg->num_envs <= 0) return fail(nullptr, BRS_ERR_ARG, "brs_create: num_envs must be > 0");
   if ((cfg->flags & BRS_FLAG_NOISE_ON) && (cfg->flags & BRS_FLAG_NOISE_OFF))
     return fail(nullptr, BRS_ERR_ARG, "brs_create: NOISE_ON and NOISE_OFF are exclusive");
@@ -192,7 +192,7 @@ int brs_create(const brs_config* cfg, brs_handle** out) {
     return fail(nullptr, BRS_ERR_HIP, std::string("brs_create: no HIP device (") + hipGetErrorString(e) + "); there is no CPU fallback");
   if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, BRS_ERR_ARG, "brs_create: device ordinal out of range");
   brs_handle* h = new brs_handle();
-  h->N = cfg->num_envs; h->device = cfg->device; h->bt = bt; h->blk = cfg->variant >= 2;
+  h->N = cfg->num_envs; h->device = cfg->device; h->bt = bt; h->blk = cfg->variant == 2 || cfg->variant == 3;
   int noise = (cfg->flags & BRS_FLAG_NOISE_ON) ? 1 : ((cfg->flags & BRS_FLAG_NOISE_OFF) ? 0 : -1);
   h->P = make_params<float>(cfg->variant, cfg->flags & BRS_FLAG_AUTO_RESET, noise, cfg->max_episode_steps, cfg->substeps,
                             cfg->timestep, cfg->seed, cfg->env_index_base);

@@ -15,7 +15,7 @@
 
 namespace brs {
 
-enum Variant { ENV01_V1 = 0, ENV01_V2 = 1, ENV03_V1 = 2, ENV03_V2 = 3 };
+enum Variant { ENV01_V1 = 0, ENV01_V2 = 1, ENV03_V1 = 2, ENV03_V2 = 3, ENV01_V3 = 4, ENV02_V1 = 5 };
 enum ContactCls { CC_WHEEL_FLOOR = 0, CC_TORSO_FLOOR = 1, CC_BLOCK_FLOOR = 2, CC_BLOCK_ROBOT = 3, CC_COUNT = 4 };
 
 // one geom-pair class of contact parameters, pre-digested for the kernel
@@ -53,6 +53,8 @@ struct Params {
   ContactClass<R> cc[CC_COUNT];
   // wheel<->block uses CC_BLOCK_ROBOT with the wheel's invweight: separate cD
   R cD_block_wheel;
+  R tran_wheel;  // wheel body_invweight0 (translational): per-episode friction (Env02) rebuilds cD = 2 mu^2 (1+mu^2) tran
+  int per_env_mu, v3;  // Env02-v1: wheel/floor friction drawn per episode; Env01-v3: target-speed schedule, pitch offset, own reward
   // env level
   int variant, family, noise, auto_reset, max_episode_steps, throw_v2;
   R Sy, Sz, block_speed;
@@ -141,7 +143,7 @@ inline Params<R> make_params(int variant, uint32_t flags_auto_reset, int noise_o
   double tran_wheel = tran_of(-r.wheel_px, 0, r.wheel_pz, 1);
   double tran_block = 1 / mB;
 
-  int family = (variant == ENV01_V1 || variant == ENV01_V2) ? 1 : 3;
+  int family = (variant == ENV03_V1 || variant == ENV03_V2) ? 3 : 1;
   auto mk = [&](double mu, double tc, double dr, double d0, double d1, double width, double margin, double tran) {
     ContactClass<R> c;
     if (tc < 2 * h) tc = 2 * h;  // refsafe
@@ -154,13 +156,15 @@ inline Params<R> make_params(int variant, uint32_t flags_auto_reset, int noise_o
     c.cD = (R)(2 * mu * mu * (1 + mu * mu) * tran);
     return c;
   };
-  if (family == 1) p.cc[CC_WHEEL_FLOOR] = mk(0.9, 0.02, 0.5, 0.5, 0.5, 0.002, 0.0, tran_wheel);
+  if (family == 1 && variant != ENV02_V1) p.cc[CC_WHEEL_FLOOR] = mk(0.9, 0.02, 0.5, 0.5, 0.5, 0.002, 0.0, tran_wheel);  // explicit <pair>s
   else p.cc[CC_WHEEL_FLOOR] = mk(1.0, 0.02, 1.0, 0.9, 0.95, 0.001, 0.0, tran_wheel);
   p.cc[CC_TORSO_FLOOR] = mk(1.0, 0.02, 1.0, 0.9, 0.95, 0.001, 0.0, tran_torso);
   // block pairs: margin max(0, .002), solref mixed 50/50 -> (0.0125, 0.95), default solimp, mu max(1,1)
   p.cc[CC_BLOCK_FLOOR] = mk(1.0, 0.0125, 0.95, 0.9, 0.95, 0.001, 0.002, tran_block);
   p.cc[CC_BLOCK_ROBOT] = mk(1.0, 0.0125, 0.95, 0.9, 0.95, 0.001, 0.002, tran_block + tran_torso);
   p.cD_block_wheel = (R)(2 * 1.0 * (1 + 1.0) * (tran_block + tran_wheel));
+  p.tran_wheel = (R)tran_wheel;
+  p.per_env_mu = variant == ENV02_V1; p.v3 = variant == ENV01_V3;
 
   p.variant = variant; p.family = family;
   p.noise = (variant == ENV01_V2) ? 1 : 0;  // envs/env01_v2.py:16-20 ; Env03_v2 does NOT inherit it

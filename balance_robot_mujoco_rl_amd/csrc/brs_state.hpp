@@ -22,7 +22,8 @@ template <bool BLK> struct Layout {
   // fp32 fields
   static constexpr int F_V = 0, F_W = 3, F_WW = 6, F_A = 8, F_LASTPITCH = 8 + NV, F_EPRET = 9 + NV, F_BV = 10 + NV,
                        F_BW = 13 + NV;
-  static constexpr int NF = BLK ? 16 + NV : 10 + NV;
+  static constexpr int F_MUW = (BLK ? 16 : 10) + NV, F_DTS = F_MUW + 1, F_POFF = F_MUW + 2, F_TWS = F_MUW + 3;
+  static constexpr int NF = F_MUW + 4;
   // int32 fields
   static constexpr int I_ELAPSED = 0, I_RNG = 1, I_SIDE = 2, I_BAD = 3, NI = 4;
   static constexpr size_t bytes_per_env = (size_t)ND * 8 + (size_t)NF * 4 + (size_t)NI * 4;
@@ -55,6 +56,7 @@ BRS_HD void load_state_phys(EnvState<R, BLK>& S, const double* d, const FT* f, c
   }
   S.rng_ctr = (uint32_t)ii[L::I_RNG * N + i];
   S.side_front = ii[L::I_SIDE * N + i];
+  S.muw = (R)f[L::F_MUW * N + i];
   S.pnfr = 0; S.pnfb = 0; S.pnc = 0; S.psels = 0; S.pmR = 0; S.pmX = 0;
 }
 // ... and the env-level scalars, only needed before and after the loop
@@ -66,6 +68,7 @@ BRS_HD void load_state_env(EnvState<R, BLK>& S, const double* d, const FT* f, co
   if constexpr (BLK) S.block_timer = d[L::D_TIMER * N + i]; else S.block_timer = -1.0;
   S.elapsed = ii[L::I_ELAPSED * N + i];
   S.bad = ii[L::I_BAD * N + i];
+  S.dts = (R)f[L::F_DTS * N + i]; S.poff = (R)f[L::F_POFF * N + i]; S.tws = (R)f[L::F_TWS * N + i];
 }
 template <typename R, bool BLK, typename FT>
 BRS_HD void load_state(EnvState<R, BLK>& S, const double* d, const FT* f, const int* ii, size_t N, size_t i) {
@@ -89,6 +92,7 @@ BRS_HD void store_state(const EnvState<R, BLK>& S, double* d, FT* f, int* ii, si
   for (int k = 0; k < L::NV; k++) f[(L::F_A + k) * N + i] = (FT)S.a[k];
   f[L::F_LASTPITCH * N + i] = (FT)S.last_pitch;
   f[L::F_EPRET * N + i] = (FT)S.ep_return;
+  f[L::F_MUW * N + i] = (FT)S.muw; f[L::F_DTS * N + i] = (FT)S.dts; f[L::F_POFF * N + i] = (FT)S.poff; f[L::F_TWS * N + i] = (FT)S.tws;
   if constexpr (BLK) {
 #pragma unroll
     for (int k = 0; k < 3; k++) {
@@ -117,9 +121,11 @@ BRS_HD void env_step_mem(const Params<R>& P, Store<R>& st, Stream<R>& rng, doubl
   using SimT = Sim<R, BLK>;
   EnvState<R, BLK> S;
   load_state_phys<R, BLK, FT>(S, d, f, ii, N, i);
+  load_state_env<R, BLK, FT>(S, d, f, ii, N, i);  // re-loaded after the loop: not live across it
   rng.ctr = S.rng_ctr;
   R ctrlL, ctrlR;
   R rew = SimT::env_pre(P, S, rng, a0, a1, ctrlL, ctrlR);
+  if (P.v3) f[L::F_TWS * N + i] = (FT)S.tws;  // the schedule may have moved the target
   {  // flattened substep x Newton loop: one trip = [start a substep] + [one Newton iteration] + [finish the substep]
     typename SimT::SubCtx C;
     int k = 0;
@@ -212,6 +218,7 @@ inline void init_state(double* d, FT* f, int* ii, size_t N, uint64_t seed, int64
   for (size_t k = 0; k < (size_t)L::NI * N; k++) ii[k] = 0;
   for (size_t i = 0; i < N; i++) {
     d[(L::D_Q + 0) * N + i] = 1; d[(L::D_XQ + 0) * N + i] = 1;
+    f[L::F_MUW * N + i] = (FT)1;
     if (BLK) { d[(L::D_BQ + 0) * N + i] = 1; d[L::D_TIMER * N + i] = -1.0; }
     uint32_t o[4];
     int64_t gid = gid_base + (int64_t)i;
@@ -310,12 +317,12 @@ inline void get_state(const double* d, const FT* f, size_t N, double* qpos, doub
   }
 }
 
-// aux rows [N][10]: last_pitch, block_timer (NaN = None), elapsed, rng_ctr, side_front, accessor pitch (read-only),
-//                   ep_return, bad count, (2 unused)
+// aux rows [N][14]: last_pitch, block_timer (NaN = None), elapsed, rng_ctr, side_front, accessor pitch (read-only),
+//                   ep_return, bad count, (2 unused), wheel/floor friction, delay_target_speed, pitch_offset, target_wheel_speed
 template <bool BLK, typename FT> inline void get_aux(const double* d, const FT* f, const int* ii, size_t N, double* aux) {
   using L = Layout<BLK>;
   for (size_t i = 0; i < N; i++) {
-    double* a = aux + 10 * i;
+    double* a = aux + 14 * i;
     a[0] = f[L::F_LASTPITCH * N + i];
     double t = BLK ? d[L::D_TIMER * N + i] : -1.0;
     { union { double f; uint64_t u; } qn; qn.u = 0x7ff8000000000000ull; a[1] = t < 0 ? qn.f : t; }
@@ -325,16 +332,18 @@ template <bool BLK, typename FT> inline void get_aux(const double* d, const FT* 
     double p, y;
     Sim<double, BLK>::pitch_yaw(xq, p, y);
     a[5] = p; a[6] = f[L::F_EPRET * N + i]; a[7] = ii[L::I_BAD * N + i]; a[8] = a[9] = 0;
+    a[10] = f[L::F_MUW * N + i]; a[11] = f[L::F_DTS * N + i]; a[12] = f[L::F_POFF * N + i]; a[13] = f[L::F_TWS * N + i];
   }
 }
 template <bool BLK, typename FT> inline void set_aux(double* d, FT* f, int* ii, size_t N, const double* aux) {
   using L = Layout<BLK>;
   for (size_t i = 0; i < N; i++) {
-    const double* a = aux + 10 * i;
+    const double* a = aux + 14 * i;
     f[L::F_LASTPITCH * N + i] = (FT)a[0];
     if (BLK) d[L::D_TIMER * N + i] = isnan_bits(a[1]) ? -1.0 : a[1];
     ii[L::I_ELAPSED * N + i] = (int)a[2]; ii[L::I_RNG * N + i] = (int)(uint32_t)a[3]; ii[L::I_SIDE * N + i] = a[4] != 0;
     f[L::F_EPRET * N + i] = (FT)a[6];
+    f[L::F_MUW * N + i] = (FT)a[10]; f[L::F_DTS * N + i] = (FT)a[11]; f[L::F_POFF * N + i] = (FT)a[12]; f[L::F_TWS * N + i] = (FT)a[13];
   }
 }
 template <bool BLK> inline void get_xpose(const double* d, size_t N, double* xq, double* xp) {

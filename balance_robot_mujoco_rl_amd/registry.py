@@ -1,6 +1,6 @@
 """id -> variant table, mirroring the reference's gymnasium registrations (src/balance_robot/__init__.py:5-52).
 
-Only the ids on the north-star path are registered: Env01-v1/v2, Env03-v1/v2."""
+Registered: the north-star ids Env01-v1/v2, Env03-v1/v2 and the f3 variants Env01-v3, Env02-v1."""
 from dataclasses import dataclass
 
 
@@ -18,6 +18,8 @@ ENV_SPECS = {
     "Env01-v2": EnvSpec("Env01-v2", 1, 6000, 6000, True),
     "Env03-v1": EnvSpec("Env03-v1", 2, 6000, 6000, False),
     "Env03-v2": EnvSpec("Env03-v2", 3, 1200, 6000, False),
+    "Env01-v3": EnvSpec("Env01-v3", 4, 6000, 6000, False),
+    "Env02-v1": EnvSpec("Env02-v1", 5, 6000, 6000, False),
 }
 
 

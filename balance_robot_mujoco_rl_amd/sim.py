@@ -116,12 +116,12 @@ class BatchedSim:
         self._check(self.L.brs_set_state(self.h, _dp(qpos), _dp(qvel), _dp(warm), _dp(time)), "brs_set_state")
 
     def get_aux(self):
-        aux = np.zeros((self.n, 10))
+        aux = np.zeros((self.n, 14))
         self._check(self.L.brs_get_aux(self.h, _dp(aux)), "brs_get_aux")
         return aux
 
     def set_aux(self, aux):
-        a = np.ascontiguousarray(np.asarray(aux, dtype=np.float64).reshape(self.n, 10))
+        a = np.ascontiguousarray(np.asarray(aux, dtype=np.float64).reshape(self.n, 14))
         self._check(self.L.brs_set_aux(self.h, _dp(a)), "brs_set_aux")
 
     def get_xpose(self):

@@ -36,7 +36,9 @@ extern "C" {
 
 typedef struct brs_handle brs_handle;
 
-typedef enum { BRS_ENV01_V1 = 0, BRS_ENV01_V2 = 1, BRS_ENV03_V1 = 2, BRS_ENV03_V2 = 3 } brs_variant;
+typedef enum { BRS_ENV01_V1 = 0, BRS_ENV01_V2 = 1, BRS_ENV03_V1 = 2, BRS_ENV03_V2 = 3,
+               BRS_ENV01_V3 = 4, /* envs/env01_v3.py: target-speed schedule, pitch offset, shaped reward */
+               BRS_ENV02_V1 = 5  /* envs/env02_v1.py: wheel/floor friction U(0.5,1) drawn per episode */ } brs_variant;
 
 typedef enum {
   BRS_OK = 0,
@@ -95,8 +97,9 @@ int brs_physics(brs_handle* h, const float* ctrl_dev, int32_t nsub, void* stream
  * time [N] f64.  Any pointer may be NULL.  set_state also refreshes the accessor pose (mj_forward). */
 int brs_get_state(brs_handle* h, double* qpos, double* qvel, double* warm, double* time);
 int brs_set_state(brs_handle* h, const double* qpos, const double* qvel, const double* warm, const double* time);
-/* aux [N][10] f64: last_pitch, block_timer (NaN = None), elapsed_steps, rng_ctr, attack_side_front,
- * accessor pitch (read-only), episode return, bad-state count (read-only), 0, 0 */
+/* aux [N][14] f64: last_pitch, block_timer (NaN = None), elapsed_steps, rng_ctr, attack_side_front,
+ * accessor pitch (read-only), episode return, bad-state count (read-only), 0, 0, wheel/floor friction (Env02),
+ * delay_target_speed, pitch_offset, target_wheel_speed (Env01-v3) */
 int brs_get_aux(brs_handle* h, double* aux);
 int brs_set_aux(brs_handle* h, const double* aux);
 /* accessor pose = data.body("robot_body").xquat [N][4] / .xpos [N][3] as the reference's get_pitch()/get_yaw() read it */

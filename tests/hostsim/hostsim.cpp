@@ -139,7 +139,7 @@ template <typename R, bool BLK> struct HostSim : IHost {
 extern "C" {
 void* hs_create(int variant, int n, int use_double, uint64_t seed, int64_t gid_base, int auto_reset, int noise,
                 int max_steps, int nsub, double h) {
-  bool blk = variant >= 2;
+  bool blk = variant == 2 || variant == 3;
   if (use_double) {
     if (blk) return new HostSim<double, true>(variant, n, seed, gid_base, auto_reset, noise, max_steps, nsub, h);
     return new HostSim<double, false>(variant, n, seed, gid_base, auto_reset, noise, max_steps, nsub, h);

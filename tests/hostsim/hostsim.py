@@ -7,7 +7,7 @@ import numpy as np
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_DIR, "libbrs_hostsim.so")
-VARIANTS = {"Env01-v1": 0, "Env01-v2": 1, "Env03-v1": 2, "Env03-v2": 3}
+VARIANTS = {"Env01-v1": 0, "Env01-v2": 1, "Env03-v1": 2, "Env03-v2": 3, "Env01-v3": 4, "Env02-v1": 5}
 _lib = None
 
 
@@ -63,7 +63,7 @@ class HostSim:
         return qpos, qvel, warm, t
 
     def get_aux(self):
-        a = np.zeros((self.n, 10))
+        a = np.zeros((self.n, 14))
         self.L.hs_get_aux(self.h, _p(a, C.c_double))
         return a
 

@@ -38,11 +38,12 @@ def test_library_and_sizes():
     s.close()
 
 
-@pytest.mark.parametrize("env_id,n,steps", [("Env01-v2", 512, 120), ("Env03-v2", 512, 100)])
+@pytest.mark.parametrize("env_id,n,steps", [("Env01-v2", 512, 120), ("Env03-v2", 512, 100), ("Env02-v1", 256, 80)])
 def test_teacher_forced_physics_parity(env_id, n, steps):
     """zero... random-action rollout, auto-reset off (robots fall and lie on the floor), noise off: per-step state parity"""
     torch, sim, orc = _mk(env_id, n, seed=3, auto_reset=False, obs_noise=False)
     orc.reset()
+    sim.set_aux(orc.get_aux())  # per-episode friction (Env02) lives in aux
     rng = np.random.default_rng(5)
     worst_q, worst_v, over = 0.0, 0.0, 0
     for t in range(steps):
@@ -67,7 +68,7 @@ def test_teacher_forced_physics_parity(env_id, n, steps):
     assert worst_q < 2e-3
 
 
-@pytest.mark.parametrize("env_id", ["Env01-v1", "Env01-v2", "Env03-v1", "Env03-v2"])
+@pytest.mark.parametrize("env_id", ["Env01-v1", "Env01-v2", "Env03-v1", "Env03-v2", "Env01-v3", "Env02-v1"])
 def test_env_step_parity_with_shared_rng(env_id):
     """full env step (reward, obs with noise, termination, block state machine, time limit, auto-reset) against the
     oracle, teacher-forced, with the SAME Philox streams on both sides"""
@@ -77,6 +78,8 @@ def test_env_step_parity_with_shared_rng(env_id):
     oo = orc.reset()
     np.testing.assert_allclose(og, oo, atol=2e-5, rtol=1e-5)
     rng = np.random.default_rng(9)
+    if env_id == "Env01-v3":  # start near the target-speed schedule's thresholds (1.0, 3.0, 4.5, 5.5 s)
+        orc.set_state(time=rng.choice([0.96, 2.96, 4.46, 5.46], size=n) + rng.integers(0, 4, size=n) * 0.005)
     n_done = 0
     for t in range(steps):
         qpos, qvel, warm, tm = orc.get_state()

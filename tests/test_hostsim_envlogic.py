@@ -88,3 +88,39 @@ def test_block_timer_timeline(golden):
         np.testing.assert_allclose(qvel[0, 8:11], row["block_qvel"][:3], atol=2e-5, rtol=1e-6)
         nthrows += bool(row["uniforms"])
     assert nthrows == 2
+
+
+CLS2VARIANT_F3 = {"Env02": "Env02-v1", "Env01_v3": "Env01-v3"}
+
+
+@pytest.mark.parametrize("double", [True, False])
+@pytest.mark.parametrize("idx", range(7))
+def test_sequences_f3(golden, idx, double):
+    """kernel source vs the reference-generated goldens for Env02-v1 / Env01-v3"""
+    rec = golden["sequences_f3"][idx]
+    h = HostSim(CLS2VARIANT_F3[rec["cls"]], 1, seed=5, double=double)
+    r = rec["reset"]
+    pre = []
+    if rec["cls"] == "Env01_v3":
+        a, b = rec["reset_gym_scalars"]
+        pre = [(a + 10.0) / 20.0, (b + 0.0349066) / (2 * 0.0349066)]
+    h.script_uniforms(0, np.concatenate([pre, (np.array(r["gym_uniform"]) + 0.01) / 0.02, np.array(r["uniforms"])]))
+    obs = h.reset()
+    assert h.script_remaining(0) == 0
+    np.testing.assert_allclose(obs[0], np.array(r["obs"], np.float32), rtol=1e-5, atol=2e-5)
+    aux = h.get_aux()
+    ex = r["extras"]
+    if rec["cls"] == "Env02":
+        assert abs(aux[0, 10] - ex["friction"]) < 1e-6
+    else:
+        np.testing.assert_allclose(aux[0, 11:14], [ex["delay_target_speed"], ex["pitch_offset"], 0.0], atol=2e-5)
+    h.set_state(time=np.array([rec["time0"]]))
+    for k, st in enumerate(rec["steps"]):
+        h.script_uniforms(0, st["uniforms"])
+        obs, rew, term, trunc, ctrl = h.step_stub(0, st["action"], st["post"]["qpos"], st["post"]["qvel"], st["post"]["xquat"], st["post"]["xpos"])
+        ref = np.array(st["obs"], np.float32)
+        np.testing.assert_allclose(obs[[0, 2, 3, 4, 5]], ref[[0, 2, 3, 4, 5]], rtol=2e-5, atol=2e-5, err_msg=f"step {k}")
+        if not (k == 0 and rec["time0"] > 0):
+            np.testing.assert_allclose(obs[1], ref[1], rtol=1e-4, atol=1e-8 if double else 3e-4)
+        assert abs(rew - st["reward"]) < (1e-6 if double else 2e-4) * max(1.0, abs(st["reward"])), (k, rew, st["reward"])
+        assert abs(h.get_aux()[0, 13] - st["extras"]["target_wheel_speed"]) < 1e-4, k

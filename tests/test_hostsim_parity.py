@@ -15,6 +15,7 @@ def _rollout_parity(env_id, n, steps, double, seed=11):
     o = O.Oracle(env_id, n, seed=seed, noise=False, threads=8)
     h = HostSim(env_id, n, seed=seed, noise=False, double=double)
     o.reset()
+    h.set_aux(o.get_aux())  # per-episode scalars (Env02's friction) live in aux
     dqs, dvs = [], []
     for t in range(steps):
         qpos, qvel, warm, tm = o.get_state()
@@ -29,7 +30,7 @@ def _rollout_parity(env_id, n, steps, double, seed=11):
     return np.array(dqs).ravel(), np.array(dvs).ravel()
 
 
-@pytest.mark.parametrize("env_id,steps", [("Env01-v2", 70), ("Env03-v2", 60)])
+@pytest.mark.parametrize("env_id,steps", [("Env01-v2", 70), ("Env03-v2", 60), ("Env02-v1", 50)])
 def test_double_instantiation_matches_oracle(env_id, steps):
     dq, dv = _rollout_parity(env_id, 16, steps, True)
     assert dq.max() < 1e-7 and dv.max() < 1e-4, (dq.max(), dv.max())

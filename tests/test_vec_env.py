@@ -19,7 +19,7 @@ def test_registry_matches_reference(golden):
     for k, s in ENV_SPECS.items():
         assert reg[k]["max_episode_steps"] == s.max_episode_steps and reg[k]["reward_threshold"] == s.reward_threshold
     assert spec("Env01-v2").obs_noise and not spec("Env03-v2").obs_noise  # Env03_v2 does not inherit Env01_v2's noise
-    assert sorted(ENV_SPECS) == ["Env01-v1", "Env01-v2", "Env03-v1", "Env03-v2"]
+    assert sorted(ENV_SPECS) == ["Env01-v1", "Env01-v2", "Env01-v3", "Env02-v1", "Env03-v1", "Env03-v2"]
 
 
 def test_shard_ranges():
