@@ -491,6 +491,23 @@ template <typename R, bool BLK> struct Sim {
   }
 
   // plane <-> torso box: corners below the centre with dist < margin, at most 4 (MuJoCo's plane-box primitive)
+  // which of the 8 box corners (+-sx, +-sy, +-sz) touch the plane: corners below the box centre with dist < margin, the
+  // first 4 in index order (MuJoCo's plane-box primitive).  Returns the count and the indices packed 3 bits each, so that
+  // the (expensive) contact records are built by a loop over the PRESENT corners only: lanes of a wave hold boxes in
+  // different orientations, an unrolled 8-corner loop would run the record code for every corner some lane uses.
+  static BRS_HD int box_corners(R nx, R ny, R nz, R sx, R sy, R sz, R dc, R margin, int& list) {
+    int cnt = 0;
+    list = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      R ld = ((i & 1) ? nx : -nx) * sx + ((i & 2) ? ny : -ny) * sy + ((i & 4) ? nz : -nz) * sz;
+      bool hit = dc + ld < margin && ld <= 0 && cnt < 4;
+      list |= hit ? (i << (3 * cnt)) : 0;
+      cnt += hit ? 1 : 0;
+    }
+    return cnt;
+  }
+  // plane <-> torso box
   static BRS_HD void collide_torso(const Params<R>& P, Store<R>& st, Frame& F, const R* u, const R* w, const R* ww, R zT) {
     const ContactClass<R>& c = P.cc[CC_TORSO_FLOOR];
     R nx = F.nT()[0], ny = F.nT()[1], nz = F.nT()[2];
@@ -498,45 +515,38 @@ template <typename R, bool BLK> struct Sim {
     // cheap reject: lowest corner
     R low = dc - (abs_(nx) * P.torso_sx + abs_(ny) * P.torso_sy + abs_(nz) * P.torso_sz);
     if (!(low < c.margin)) return;
-    int cnt = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
+    int list, cnt = box_corners(nx, ny, nz, P.torso_sx, P.torso_sy, P.torso_sz, dc, c.margin, list);
+    for (int k = 0; k < cnt; k++) {
+      int i = (list >> (3 * k)) & 7;
       R lx = (i & 1) ? P.torso_sx : -P.torso_sx, ly = (i & 2) ? P.torso_sy : -P.torso_sy, lz = (i & 4) ? P.torso_sz : -P.torso_sz;
-      R ld = nx * lx + ny * ly + nz * lz;
-      R d = dc + ld;
-      if (d < c.margin && ld <= 0 && cnt < 4) {
-        R pt[3] = {lx, ly, P.torso_cz + lz};
-        add_robot_floor(P, st, F, u, w, ww, 0, CC_TORSO_FLOOR, pt, d);
-        cnt++;
-      }
+      R d = dc + nx * lx + ny * ly + nz * lz;
+      R pt[3] = {lx, ly, P.torso_cz + lz};
+      add_robot_floor(P, st, F, u, w, ww, 0, CC_TORSO_FLOOR, pt, d);
     }
   }
-
   static BRS_HD void collide_block_floor(const Params<R>& P, Store<R>& st, Frame& F, const R* uB, const R* wB, R zB) {
     const ContactClass<R>& c = P.cc[CC_BLOCK_FLOOR];
     R nx = F.nB()[0], ny = F.nB()[1], nz = F.nB()[2], s = P.block_s;
     R low = zB - (abs_(nx) + abs_(ny) + abs_(nz)) * s;
     if (!(low < c.margin)) return;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
+    int list, cnt = box_corners(nx, ny, nz, s, s, s, zB, c.margin, list);
+    for (int k = 0; k < cnt; k++) {
+      int i = (list >> (3 * k)) & 7;
       R lx = (i & 1) ? s : -s, ly = (i & 2) ? s : -s, lz = (i & 4) ? s : -s;
-      R ld = nx * lx + ny * ly + nz * lz;
-      R d = zB + ld;
-      if (d < c.margin && ld <= 0 && F.nfb < N_BLOCK_SLOTS) {
-        R r[3] = {lx - nx * d * (R)0.5, ly - ny * d * (R)0.5, lz - nz * d * (R)0.5};
-        R wr[3];
-        cross_(wB, r, wr);
-        R pv[3] = {uB[0] + wr[0], uB[1] + wr[1], uB[2] + wr[2]};
-        R vn = dot_(F.nB(), pv), vt1 = dot_(F.t1B(), pv), vt2 = -dot_(F.xB(), pv);
-        R imp = impedance_(c, d);
-        int sl = SLOT_BLOCK + F.nfb;
-        st.set(sl, 0, r[0]); st.set(sl, 1, r[1]); st.set(sl, 2, r[2]);
-        st.set(sl, 3, -c.B * vn - c.K * imp * (d - c.margin));
-        st.set(sl, 4, -c.B * c.mu * vt1);
-        st.set(sl, 5, -c.B * c.mu * vt2);
-        st.set(sl, 6, imp * rcp_((1 - imp) * c.cD));
-        F.nfb++;
-      }
+      R d = zB + nx * lx + ny * ly + nz * lz;
+      R r[3] = {lx - nx * d * (R)0.5, ly - ny * d * (R)0.5, lz - nz * d * (R)0.5};
+      R wr[3];
+      cross_(wB, r, wr);
+      R pv[3] = {uB[0] + wr[0], uB[1] + wr[1], uB[2] + wr[2]};
+      R vn = dot_(F.nB(), pv), vt1 = dot_(F.t1B(), pv), vt2 = -dot_(F.xB(), pv);
+      R imp = impedance_(c, d);
+      int sl = SLOT_BLOCK + F.nfb;
+      st.set(sl, 0, r[0]); st.set(sl, 1, r[1]); st.set(sl, 2, r[2]);
+      st.set(sl, 3, -c.B * vn - c.K * imp * (d - c.margin));
+      st.set(sl, 4, -c.B * c.mu * vt1);
+      st.set(sl, 5, -c.B * c.mu * vt2);
+      st.set(sl, 6, imp * rcp_((1 - imp) * c.cD));
+      F.nfb++;
     }
   }
 

@@ -7,9 +7,13 @@ while IFS= read -r FL; do
   python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print('%-80s %.4g env-steps/s' % ('''$FL''', d['value']))"
 done <<'LIST'
 
--Xarch_device -fno-vectorize
--mllvm -amdgpu-schedule-relaxed-occupancy=true
--Xarch_device -fno-unroll-loops
--mllvm -amdgpu-use-divergent-register-indexing
--mllvm -amdgpu-dpp-combine=false
+-mllvm -misched-topdown
+-mllvm -misched-bottomup
+-mllvm -greedy-regclass-priority-trumps-globalness=1
+-mllvm -enable-local-reassign=1
+-mllvm -amdgpu-schedule-metric-bias=0
+-mllvm -amdgpu-schedule-metric-bias=100
+-mllvm -disable-machine-sink
+-mllvm -inline-threshold=100000
+-mllvm -amdgpu-disable-unclustered-high-rp-reschedule
 LIST
