@@ -21,12 +21,37 @@ class ActorCritic(nn.Module):
         mk = lambda o: nn.Sequential(nn.Linear(6, 64), nn.Tanh(), nn.Linear(64, 64), nn.Tanh(), nn.Linear(64, o))
         self.pi, self.v = mk(2), mk(1)
         self.log_std = nn.Parameter(torch.full((2,), float(log_std_init)))
+        self.register_buffer("ret_scale", torch.ones(()))   # critic output unit (running std of the returns)
+
+    def value(self, obs):
+        return self.v(obs).squeeze(-1) * self.ret_scale
 
     def dist(self, obs):
         return torch.distributions.Normal(self.pi(obs), self.log_std.exp())
 
 
-def train(sim, model, opt, iters, n_steps, epochs, minibatch, gamma, lam, clip, log, tag, ent=0.0):
+class MixedSim:
+    """several BatchedSims stepped back to back and presented as one batch (second phase: keep part of the envs in the
+    first phase's environment so the policy is not allowed to forget it)"""
+
+    def __init__(self, sims):
+        self.sims = sims; self.n = sum(s.n for s in sims); self.device = sims[0].device
+        self._cuts = [s.n for s in sims]
+
+    def reset(self):
+        return torch.cat([s.reset() for s in self.sims])
+
+    def step(self, a):
+        outs = [s.step(p.contiguous()) for s, p in zip(self.sims, a.split(self._cuts))]
+        return tuple(torch.cat([o[k] for o in outs]) for k in range(5))
+
+    def close(self):
+        for s in self.sims:
+            s.close()
+
+
+def train(sim, model, opt, iters, n_steps, epochs, minibatch, gamma, lam, clip, log, tag, ent=0.0, reward_clip=None,
+          critic_warmup=0, lr_end=None, norm_returns=False):
     n = sim.n
     dev = sim.device
     obs = sim.reset().clone()
@@ -34,23 +59,29 @@ def train(sim, model, opt, iters, n_steps, epochs, minibatch, gamma, lam, clip, 
     done_len_sum = done_ret_sum = done_cnt = 0.0
     B = {k: torch.zeros((n_steps, n) + s, device=dev) for k, s in dict(obs=(6,), act=(2,), logp=(), rew=(), val=(), done=(), boot=()).items()}
     t_start = time.time(); total = 0
+    lr0 = opt.param_groups[0]["lr"]
     for it in range(iters):
+        if lr_end is not None:   # linear anneal over the phase
+            for g_ in opt.param_groups:
+                g_["lr"] = lr0 + (lr_end - lr0) * it / max(1, iters - 1)
         with torch.no_grad():
             for t in range(n_steps):
                 d = model.dist(obs)
                 a = d.sample()
-                B["obs"][t] = obs; B["act"][t] = a; B["logp"][t] = d.log_prob(a).sum(-1); B["val"][t] = model.v(obs).squeeze(-1)
+                B["obs"][t] = obs; B["act"][t] = a; B["logp"][t] = d.log_prob(a).sum(-1); B["val"][t] = model.value(obs)
                 o, r, te, tr, to = sim.step(a.clamp(-1, 1).contiguous())   # SB3 clips actions to the Box before env.step
                 done = (te | tr).bool()
                 # time-limit truncation (not a failure): bootstrap from the terminal observation, like SB3
-                boot = torch.where(tr.bool() & ~te.bool(), model.v(to).squeeze(-1), torch.zeros_like(r))
-                B["rew"][t] = r; B["done"][t] = done.float(); B["boot"][t] = boot
+                boot = torch.where(tr.bool() & ~te.bool(), model.value(to), torch.zeros_like(r))
+                # learner-side reward clipping (a TransformReward-style wrapper); logged returns stay the env's own
+                B["rew"][t] = r if reward_clip is None else r.clamp(max=reward_clip)
+                B["done"][t] = done.float(); B["boot"][t] = boot
                 ep_len += 1; ep_ret += r
                 if done.any():
                     done_len_sum += ep_len[done].sum().item(); done_ret_sum += ep_ret[done].sum().item(); done_cnt += done.sum().item()
                     ep_len[done] = 0; ep_ret[done] = 0
                 obs = o.clone()
-            last_v = model.v(obs).squeeze(-1)
+            last_v = model.value(obs)
             adv = torch.zeros_like(B["rew"]); g = torch.zeros(n, device=dev)
             for t in reversed(range(n_steps)):
                 nv = last_v if t == n_steps - 1 else B["val"][t + 1]
@@ -59,6 +90,8 @@ def train(sim, model, opt, iters, n_steps, epochs, minibatch, gamma, lam, clip, 
                 g = delta + gamma * lam * nonterm * g
                 adv[t] = g
             ret = adv + B["val"]
+            if norm_returns:
+                model.ret_scale.lerp_(ret.std().clamp(min=1.0), 0.05 if it else 1.0)
         flat = {k: v.reshape((-1,) + v.shape[2:]) for k, v in B.items()}
         fadv = adv.reshape(-1); fret = ret.reshape(-1)
         N = fadv.numel()
@@ -71,16 +104,49 @@ def train(sim, model, opt, iters, n_steps, epochs, minibatch, gamma, lam, clip, 
                 ratio = (logp - flat["logp"][idx]).exp()
                 a_ = fadv[idx]; a_ = (a_ - a_.mean()) / (a_.std() + 1e-8)
                 pl = -torch.min(ratio * a_, ratio.clamp(1 - clip, 1 + clip) * a_).mean()
-                vl = 0.5 * (model.v(flat["obs"][idx]).squeeze(-1) - fret[idx]).pow(2).mean()
-                loss = pl + 0.5 * vl - ent * d.entropy().sum(-1).mean()
-                opt.zero_grad(set_to_none=True); loss.backward(); nn.utils.clip_grad_norm_(model.parameters(), 0.5); opt.step()
+                vl = 0.5 * (model.v(flat["obs"][idx]).squeeze(-1) - fret[idx] / model.ret_scale).pow(2).mean()
+                if it < critic_warmup:   # new env: let the critic catch up before the actor moves
+                    loss = 0.5 * vl
+                else:
+                    loss = pl + 0.5 * vl - ent * d.entropy().sum(-1).mean()
+                opt.zero_grad(set_to_none=True); loss.backward()
+                # actor and critic are separate towers: clip them separately so large value targets cannot starve the actor
+                nn.utils.clip_grad_norm_(list(model.pi.parameters()) + [model.log_std], 0.5)
+                nn.utils.clip_grad_norm_(model.v.parameters(), 0.5); opt.step()
         total += n * n_steps
         if done_cnt > 0:
             row = dict(tag=tag, iter=it, env_steps=total, wall_s=round(time.time() - t_start, 2),
-                       mean_ep_len=done_len_sum / done_cnt, mean_ep_ret=done_ret_sum / done_cnt, episodes=int(done_cnt))
+                       mean_ep_len=done_len_sum / done_cnt, mean_ep_ret=done_ret_sum / done_cnt, episodes=int(done_cnt),
+                       log_std=round(float(model.log_std.detach().mean()), 3))
             log.append(row); print(json.dumps(row), flush=True) if (it % 10 == 0 or it == iters - 1) else None
             done_len_sum = done_ret_sum = done_cnt = 0.0
     return total
+
+
+@torch.no_grad()
+def evaluate(env_id, model, n, steps, seed=123):
+    """deterministic policy (mean action) on fresh envs: episode-length statistics and the share of episodes that
+    run into the time limit (= balanced for the whole episode)"""
+    sim = BatchedSim(env_id, n, device=0, seed=seed, auto_reset=True)
+    obs = sim.reset().clone()
+    ep_len = torch.zeros(n, device=sim.device); ep_ret = torch.zeros(n, device=sim.device)
+    lens, rets, ntrunc, nterm = [], [], 0, 0
+    ever_done = torch.zeros(n, dtype=torch.bool, device=sim.device)
+    for _ in range(steps):
+        o, r, te, tr, _to = sim.step(model.pi(obs).clamp(-1, 1).contiguous())
+        ep_len += 1; ep_ret += r
+        done = (te | tr).bool()
+        if done.any():
+            lens.append(ep_len[done].clone()); rets.append(ep_ret[done].clone())
+            ntrunc += int((tr.bool() & ~te.bool()).sum()); nterm += int(te.bool().sum())
+            ep_len[done] = 0; ep_ret[done] = 0; ever_done |= done
+        obs = o.clone()
+    still = int((~ever_done).sum())   # first episode still running after `steps` steps
+    sim.close()
+    lens = torch.cat(lens) if lens else torch.zeros(0); rets = torch.cat(rets) if rets else torch.zeros(0)
+    return dict(env=env_id, envs=n, steps=steps, episodes=int(lens.numel()), first_episode_still_running=still, reached_time_limit=ntrunc, fell=nterm,
+                frac_reached_time_limit=ntrunc / max(1, ntrunc + nterm), mean_ep_len=float(lens.mean()) if lens.numel() else None,
+                median_ep_len=float(lens.median()) if lens.numel() else None, mean_ep_ret=float(rets.mean()) if rets.numel() else None)
 
 
 def main():
@@ -93,6 +159,16 @@ def main():
     ap.add_argument("--lr", type=float, default=3e-4)
     ap.add_argument("--log-std-init", type=float, default=-0.5); ap.add_argument("--ent", type=float, default=0.0)
     ap.add_argument("--gamma", type=float, default=0.99); ap.add_argument("--lam", type=float, default=0.95)
+    ap.add_argument("--lr2", type=float, default=None, help="learning rate of the second phase (default: --lr)")
+    ap.add_argument("--log-std2", type=float, default=None, help="reset the policy log-std to this at the second phase")
+    ap.add_argument("--critic-warmup2", type=int, default=0, help="value-only iterations at the start of the second phase")
+    ap.add_argument("--lr2-end", type=float, default=None, help="anneal the second phase's learning rate linearly to this")
+    ap.add_argument("--norm-returns", action="store_true", help="critic in units of the running std of the returns")
+    ap.add_argument("--mix2", type=float, default=0.0, help="share of the envs kept in --env during the second phase")
+    ap.add_argument("--reward-clip", type=float, default=None, help="learner-side upper clip of the per-step reward")
+    ap.add_argument("--eval-steps", type=int, default=0, help="after training: deterministic evaluation for this many steps")
+    ap.add_argument("--eval-envs", type=int, default=4096)
+    ap.add_argument("--save", default="", help="write the policy/value weights (torch state_dict) here")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     torch.manual_seed(0)
@@ -100,14 +176,36 @@ def main():
     model = ActorCritic(a.log_std_init).to(dev)
     opt = torch.optim.Adam(model.parameters(), lr=a.lr)
     log = []
-    for env_id, iters in ((a.env, a.iters), (a.then, a.iters2)):
+    for phase, (env_id, iters) in enumerate(((a.env, a.iters), (a.then, a.iters2))):
         if not env_id:
             continue
-        sim = BatchedSim(env_id, a.envs, device=0, seed=0, auto_reset=True)
-        train(sim, model, opt, iters, a.n_steps, a.epochs, a.minibatch, a.gamma, a.lam, 0.2, log, env_id, a.ent)
+        warm = 0
+        if phase == 1:
+            warm = a.critic_warmup2
+            if a.lr2 is not None:
+                for g in opt.param_groups:
+                    g["lr"] = a.lr2
+            if a.log_std2 is not None:
+                with torch.no_grad():
+                    model.log_std.fill_(a.log_std2)
+        if phase == 1 and a.mix2 > 0:
+            keep = int(a.envs * a.mix2) // 64 * 64
+            sim = MixedSim([BatchedSim(a.env, keep, device=0, seed=1, auto_reset=True),
+                            BatchedSim(env_id, a.envs - keep, device=0, seed=0, auto_reset=True)])
+            env_id = f"{a.env}+{env_id}"
+        else:
+            sim = BatchedSim(env_id, a.envs, device=0, seed=0, auto_reset=True)
+        train(sim, model, opt, iters, a.n_steps, a.epochs, a.minibatch, a.gamma, a.lam, 0.2, log, env_id, a.ent, a.reward_clip,
+              warm, a.lr2_end if phase == 1 else None, a.norm_returns)
         sim.close()
+    evals = []
+    if a.eval_steps > 0:
+        for env_id in dict.fromkeys(e for e in (a.env, a.then) if e):
+            evals.append(evaluate(env_id, model, a.eval_envs, a.eval_steps)); print(json.dumps(evals[-1]), flush=True)
+    if a.save:
+        torch.save(model.state_dict(), a.save)
     if a.out:
-        json.dump(dict(args=vars(a), log=log), open(a.out, "w"), indent=1)
+        json.dump(dict(args=vars(a), log=log, eval=evals), open(a.out, "w"), indent=1)
 
 
 if __name__ == "__main__":
