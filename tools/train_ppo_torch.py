@@ -9,6 +9,7 @@ actor / critic towers, state-independent log-std) consuming BatchedSim tensors d
 """
 import argparse, json, os, sys, time
 import torch
+import torch.distributed as dist
 import torch.nn as nn
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -28,6 +29,31 @@ class ActorCritic(nn.Module):
 
     def dist(self, obs):
         return torch.distributions.Normal(self.pi(obs), self.log_std.exp())
+
+
+def _world():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def allreduce_mean_grads(model):
+    """data-parallel learner: every rank steps its own env shard; the only exchange is ONE all-reduce
+    of the flattened gradient (~10 k floats) per optimiser step -- RCCL over xGMI under backend "nccl", gloo in the CPU test"""
+    w = _world()
+    if w == 1:
+        return
+    grads = [p.grad for p in model.parameters() if p.grad is not None]
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat)
+    flat /= w
+    off = 0
+    for g in grads:
+        g.copy_(flat[off:off + g.numel()].view_as(g)); off += g.numel()
+
+
+def _allreduce_mean_(t):
+    if _world() > 1:
+        dist.all_reduce(t); t /= _world()
+    return t
 
 
 class MixedSim:
@@ -91,7 +117,7 @@ def train(sim, model, opt, iters, n_steps, epochs, minibatch, gamma, lam, clip, 
                 adv[t] = g
             ret = adv + B["val"]
             if norm_returns:
-                model.ret_scale.lerp_(ret.std().clamp(min=1.0), 0.05 if it else 1.0)
+                model.ret_scale.lerp_(_allreduce_mean_(ret.std()).clamp(min=1.0), 0.05 if it else 1.0)   # same on all ranks
         flat = {k: v.reshape((-1,) + v.shape[2:]) for k, v in B.items()}
         fadv = adv.reshape(-1); fret = ret.reshape(-1)
         N = fadv.numel()
@@ -109,22 +135,27 @@ def train(sim, model, opt, iters, n_steps, epochs, minibatch, gamma, lam, clip, 
                     loss = 0.5 * vl
                 else:
                     loss = pl + 0.5 * vl - ent * d.entropy().sum(-1).mean()
-                opt.zero_grad(set_to_none=True); loss.backward()
+                opt.zero_grad(set_to_none=True); loss.backward(); allreduce_mean_grads(model)
                 # actor and critic are separate towers: clip them separately so large value targets cannot starve the actor
                 nn.utils.clip_grad_norm_(list(model.pi.parameters()) + [model.log_std], 0.5)
                 nn.utils.clip_grad_norm_(model.v.parameters(), 0.5); opt.step()
-        total += n * n_steps
+        total += n * n_steps * _world()
+        if _world() > 1:
+            st = torch.tensor([done_len_sum, done_ret_sum, done_cnt], dtype=torch.float64, device=dev)
+            dist.all_reduce(st); done_len_sum, done_ret_sum, done_cnt = st.tolist()
         if done_cnt > 0:
             row = dict(tag=tag, iter=it, env_steps=total, wall_s=round(time.time() - t_start, 2),
                        mean_ep_len=done_len_sum / done_cnt, mean_ep_ret=done_ret_sum / done_cnt, episodes=int(done_cnt),
                        log_std=round(float(model.log_std.detach().mean()), 3))
-            log.append(row); print(json.dumps(row), flush=True) if (it % 10 == 0 or it == iters - 1) else None
+            log.append(row)
+            if (it % 10 == 0 or it == iters - 1) and (not dist.is_initialized() or dist.get_rank() == 0):
+                print(json.dumps(row), flush=True)
             done_len_sum = done_ret_sum = done_cnt = 0.0
     return total
 
 
 @torch.no_grad()
-def evaluate(env_id, model, n, steps, seed=123):
+def evaluate(env_id, model, n, steps, seed=123, device=0):
     """deterministic policy (mean action) on fresh envs: episode-length statistics and the share of episodes that
     run into the time limit (= balanced for the whole episode)"""
     sim = BatchedSim(env_id, n, device=0, seed=seed, auto_reset=True)
@@ -171,9 +202,16 @@ def main():
     ap.add_argument("--save", default="", help="write the policy/value weights (torch state_dict) here")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
-    torch.manual_seed(0)
-    dev = torch.device("cuda", 0)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:   # python -m torch.distributed.run --nproc-per-node N tools/train_ppo_torch.py ...: --envs is per rank
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    torch.manual_seed(0)   # identical initial weights on every rank
+    dev = torch.device("cuda", local)
     model = ActorCritic(a.log_std_init).to(dev)
+    torch.manual_seed(1000 + rank)   # ... different action noise
+    base = rank * a.envs
     opt = torch.optim.Adam(model.parameters(), lr=a.lr)
     log = []
     for phase, (env_id, iters) in enumerate(((a.env, a.iters), (a.then, a.iters2))):
@@ -190,22 +228,28 @@ def main():
                     model.log_std.fill_(a.log_std2)
         if phase == 1 and a.mix2 > 0:
             keep = int(a.envs * a.mix2) // 64 * 64
-            sim = MixedSim([BatchedSim(a.env, keep, device=0, seed=1, auto_reset=True),
-                            BatchedSim(env_id, a.envs - keep, device=0, seed=0, auto_reset=True)])
+            sim = MixedSim([BatchedSim(a.env, keep, device=local, seed=1, env_index_base=base, auto_reset=True),
+                            BatchedSim(env_id, a.envs - keep, device=local, seed=0, env_index_base=base, auto_reset=True)])
             env_id = f"{a.env}+{env_id}"
         else:
-            sim = BatchedSim(env_id, a.envs, device=0, seed=0, auto_reset=True)
+            sim = BatchedSim(env_id, a.envs, device=local, seed=0, env_index_base=base, auto_reset=True)
         train(sim, model, opt, iters, a.n_steps, a.epochs, a.minibatch, a.gamma, a.lam, 0.2, log, env_id, a.ent, a.reward_clip,
               warm, a.lr2_end if phase == 1 else None, a.norm_returns)
         sim.close()
     evals = []
+    if world > 1:
+        dist.barrier()
+    if rank != 0:
+        dist.destroy_process_group(); return
     if a.eval_steps > 0:
         for env_id in dict.fromkeys(e for e in (a.env, a.then) if e):
             evals.append(evaluate(env_id, model, a.eval_envs, a.eval_steps)); print(json.dumps(evals[-1]), flush=True)
     if a.save:
         torch.save(model.state_dict(), a.save)
     if a.out:
-        json.dump(dict(args=vars(a), log=log, eval=evals), open(a.out, "w"), indent=1)
+        json.dump(dict(args=vars(a), world_size=world, log=log, eval=evals), open(a.out, "w"), indent=1)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
