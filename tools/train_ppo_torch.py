@@ -192,6 +192,7 @@ def main():
     ap.add_argument("--gamma", type=float, default=0.99); ap.add_argument("--lam", type=float, default=0.95)
     ap.add_argument("--lr2", type=float, default=None, help="learning rate of the second phase (default: --lr)")
     ap.add_argument("--log-std2", type=float, default=None, help="reset the policy log-std to this at the second phase")
+    ap.add_argument("--fix-log-std2", action="store_true", help="do not train the log-std in the second phase (keeps exploring)")
     ap.add_argument("--critic-warmup2", type=int, default=0, help="value-only iterations at the start of the second phase")
     ap.add_argument("--lr2-end", type=float, default=None, help="anneal the second phase's learning rate linearly to this")
     ap.add_argument("--norm-returns", action="store_true", help="critic in units of the running std of the returns")
@@ -226,6 +227,8 @@ def main():
             if a.log_std2 is not None:
                 with torch.no_grad():
                     model.log_std.fill_(a.log_std2)
+            if a.fix_log_std2:
+                model.log_std.requires_grad_(False)
         if phase == 1 and a.mix2 > 0:
             keep = int(a.envs * a.mix2) // 64 * 64
             sim = MixedSim([BatchedSim(a.env, keep, device=local, seed=1, env_index_base=base, auto_reset=True),
