@@ -140,8 +140,12 @@ def main():
         # + WRITE_SIZE, separate --pmc passes), else null
         try:
             if args.env == "Env03-v2" and n == 65536:
-                prof = json.load(open(os.path.join(ROOT, "profiles", "r01_env03_summary.json")))["hbm_traffic"]
+                summ = json.load(open(os.path.join(ROOT, "profiles", "r01_env03_summary.json")))
+                prof = summ["hbm_traffic"]
                 out["roofline"]["traffic"] = prof["fetch_bytes_x2_corrected"] + prof["write_bytes"]
+                # the resource that does bind (same PMC summary): share of wave cycles with the VALU busy, one wave per SIMD
+                out["roofline"]["valu"] = {"busy_frac": summ["valu_busy_frac"], "wait_frac": summ["wait_frac"],
+                                           "valu_insts_per_wave_per_step": summ["per_wave_step"]["SQ_INSTS_VALU"]}
                 out["roofline"]["traffic_source"] = "profiles/r01_env03_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
         except Exception:
             pass
