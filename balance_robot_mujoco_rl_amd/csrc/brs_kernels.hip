@@ -58,7 +58,11 @@ __global__ void __launch_bounds__(256) brs_step_kernel(const Params<float> P, co
   int te, tr;
   env_step_mem<float, BLK, float>(P, st, rng, d, f, ii, (size_t)N, (size_t)i, a0, a1, o, to, rew, te, tr);
 #if defined(BRS_TIMING) && defined(__HIP_DEVICE_COMPILE__)
-  if ((threadIdx.x & 63) == 0) for (int k = 0; k < 16; k++) atomicAdd(&brs_dbg[k], brs_tim_slots()[k]);
+  if ((threadIdx.x & 63) == 0) {
+    for (int k = 0; k < 12; k++) atomicAdd(&brs_dbg[k], brs_tim_slots()[k]);
+    atomicMax(&brs_dbg[12], brs_tim_slots()[8]);  // slowest wave of the launch: cycles, trips (load imbalance, 1 wave per SIMD)
+    atomicMax(&brs_dbg[13], brs_tim_slots()[9]);
+  }
 #endif
 #pragma unroll
   for (int k = 0; k < 6; k++) obs[6 * (size_t)i + k] = o[k];

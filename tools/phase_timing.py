@@ -28,3 +28,13 @@ tot = buf[8]
 print(f"{env}: trips per wave-step {buf[9] / waves / steps:.1f}")
 for i, nm in [(j, names[j]) for j in (0, 1, 2, 3, 10, 11, 4, 5, 6, 7, 8)]:
     print(f"  {nm:22s} {buf[i] / waves / steps:12.0f} cycles/wave-step  {100.0 * buf[i] / tot:5.1f}% of trip time   {buf[i] / max(1, buf[9]):8.0f} cycles/trip")
+
+# load balance: with one wave per SIMD the launch lasts as long as its slowest wave
+ratios = []
+for k in range(20):
+    sim.step(acts[k % 16]); torch.cuda.synchronize(); L.brs_debug_counters(buf)
+    mean_c, max_c, mean_t, max_t = buf[8] / waves, buf[12], buf[9] / waves, buf[13]
+    ratios.append((max_c / mean_c, max_t / mean_t, mean_t, max_t))
+import statistics as st_
+print(f"  slowest wave / mean wave: cycles x{st_.mean(r[0] for r in ratios):.3f}, trips x{st_.mean(r[1] for r in ratios):.3f} "
+      f"(mean trips {st_.mean(r[2] for r in ratios):.1f}, max trips {st_.mean(r[3] for r in ratios):.1f})")
