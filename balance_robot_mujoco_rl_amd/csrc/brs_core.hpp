@@ -48,7 +48,9 @@ __device__ __forceinline__ unsigned long long* brs_tim_slots() {  // 16 x u64 pe
 }
 #define BRS_TIC(id) unsigned long long _brs_t##id = brs_stamp()
 #define BRS_PIN(x) asm volatile("" : "+v"(x))
-#define BRS_TOC(id) do { unsigned long long _d = brs_stamp() - _brs_t##id; if ((threadIdx.x & 63) == 0) brs_tim_slots()[id] += _d; } while (0)
+// the first ACTIVE lane books the interval (lane 0 may have left the loop before its wave has)
+#define BRS_LEADER() (__lane_id() == (unsigned)__ffsll((long long)__ballot(1)) - 1u)
+#define BRS_TOC(id) do { unsigned long long _d = brs_stamp() - _brs_t##id; if (BRS_LEADER()) brs_tim_slots()[id] += _d; } while (0)
 #else
 #define BRS_TIC(id) do { } while (0)
 #define BRS_TOC(id) do { } while (0)
@@ -67,7 +69,7 @@ __device__ __forceinline__ unsigned long long* brs_tim_slots() {  // 16 x u64 pe
 namespace brs {
 
 #if defined(BRS_STATS) && !defined(__HIP_DEVICE_COMPILE__)
-struct Stats { long substeps, solves[3], iters[3], passA[3], backtracks[3]; int last_iters[3]; };
+struct Stats { long substeps, solves[3], iters[3], passA[3], backtracks[3]; int last_iters[3]; long hist[17], trips; };
 inline Stats& stats() { static thread_local Stats s{}; return s; }
 #define BRS_STAT(expr) do { expr; } while (0)
 #else
@@ -1221,7 +1223,7 @@ template <typename R, bool BLK> struct Sim {
 #pragma unroll
       for (int i = 0; i < NV; i++) { S.a[i] = F.a0[i]; C.fcon[i] = 0; }
     }
-    BRS_STAT(if (!C.conv) { stats().solves[0]++; stats().last_iters[0] = 0; });
+    BRS_STAT(stats().last_iters[0] = 0; if (!C.conv) stats().solves[0]++);
   }
   static BRS_HD void sub_iter(const Params<R>& P, Store<R>& st, ES& S, SubCtx& C) {
     C.conv = Solver::iterate(P, st, C.F, C.M, S.a, C.F.a0, C.fcon, C.first, C.it, C.cost);
@@ -1268,6 +1270,7 @@ template <typename R, bool BLK> struct Sim {
     for (int i_ = 0; i_ < 4; i_++) BRS_PIN(S.q[i_]);
     BRS_PIN(S.ww[0]); BRS_PIN(S.ww[1]);
     BRS_TOC(7);
+    BRS_STAT(int li = stats().last_iters[0]; stats().hist[li > 16 ? 16 : li]++; stats().trips += li > 1 ? li : 1; stats().substeps++);
     BRS_MARK("end_done");
   }
   // un-flattened form (one lane at a time: host tests, single substeps)

@@ -22,6 +22,7 @@
 #include "../../include/brs.h"
 #if defined(BRS_TIMING)
 __device__ unsigned long long brs_dbg[16];
+__device__ unsigned long long brs_dbg_wave[4096];
 #define BRS_TIMING_LANE_WORDS 136
 #endif
 #include "brs_state.hpp"
@@ -62,6 +63,15 @@ __global__ void __launch_bounds__(256) brs_step_kernel(const Params<float> P, co
     for (int k = 0; k < 12; k++) atomicAdd(&brs_dbg[k], brs_tim_slots()[k]);
     atomicMax(&brs_dbg[12], brs_tim_slots()[8]);  // slowest wave of the launch: cycles, trips (load imbalance, 1 wave per SIMD)
     atomicMax(&brs_dbg[13], brs_tim_slots()[9]);
+    // per-wave record of the LAST launch: cycles, trips, HW_ID, XCC_ID (where did the slow waves run?)
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const unsigned w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (w < 1024) {
+      brs_dbg_wave[4 * w + 0] = brs_tim_slots()[8]; brs_dbg_wave[4 * w + 1] = brs_tim_slots()[9];
+      brs_dbg_wave[4 * w + 2] = hw; brs_dbg_wave[4 * w + 3] = xcc;
+    }
   }
 #endif
 #pragma unroll
@@ -332,6 +342,9 @@ int64_t brs_step_bytes_per_env(const brs_handle* h) {
 }
 #if defined(BRS_TIMING)
 // diagnostic builds only: read and clear the per-phase cycle sums
+int brs_debug_waves(unsigned long long* out4096) {
+  return hipMemcpyFromSymbol(out4096, HIP_SYMBOL(brs_dbg_wave), 4096 * sizeof(unsigned long long)) == hipSuccess ? BRS_OK : BRS_ERR_HIP;
+}
 int brs_debug_counters(unsigned long long* out16) {
   if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(brs_dbg), 16 * sizeof(unsigned long long)) != hipSuccess) return BRS_ERR_HIP;
   unsigned long long z[16] = {0};

@@ -150,7 +150,7 @@ BRS_HD void env_step_mem(const Params<R>& P, Store<R>& st, Stream<R>& rng, doubl
       }
       BRS_TOC(8);
 #if defined(BRS_TIMING) && defined(__HIP_DEVICE_COMPILE__)
-      if ((threadIdx.x & 63) == 0) brs_tim_slots()[9] += 1ull;
+      if (BRS_LEADER()) brs_tim_slots()[9] += 1ull;
 #endif
     }
   }

@@ -1,0 +1,50 @@
+// Diagnostic (host build of the kernel source, fp32, -DBRS_STATS): distribution of Newton iterations per substep and of
+// the flattened loop's trips per lane / per 64-lane wave for Env03-v2 under a random policy with auto-reset.
+//   g++ -O2 -std=c++17 -DBRS_STATS -ffp-contract=off -I../../balance_robot_mujoco_rl_amd/csrc iter_hist.cpp -o /tmp/iter_hist && /tmp/iter_hist
+#include <cstdio>
+#include <cstring>
+#include <random>
+#include <vector>
+#include <algorithm>
+#include "brs_state.hpp"
+using namespace brs;
+int main(int argc, char** argv) {
+  const int N = argc > 1 ? atoi(argv[1]) : 256, STEPS = argc > 2 ? atoi(argv[2]) : 60;
+  using R = float;
+  using L = Layout<true>;
+  Params<R> P = make_params<R>(3, true, -1, 0, 0, 0.0, 0, 0);
+  std::vector<double> d(L::ND * (size_t)N); std::vector<R> f(L::NF * (size_t)N); std::vector<int> ii(L::NI * (size_t)N);
+  hostconv::init_state<true>(d.data(), f.data(), ii.data(), N, 0, 0);
+  R buf[136];
+  std::vector<float> obs(6 * N);
+  for (int i = 0; i < N; i++) {
+    EnvState<R, true> S; load_state<R, true>(S, d.data(), f.data(), ii.data(), N, i);
+    Stream<R> rng; rng.open(P.seed, P.gid_base + i, S.rng_ctr);
+    Sim<R, true>::env_reset(P, S, rng, obs.data() + 6 * i); S.rng_ctr = rng.ctr;
+    store_state<R, true>(S, d.data(), f.data(), ii.data(), N, i);
+  }
+  std::mt19937 gen(1); std::uniform_real_distribution<float> U(-1, 1);
+  long hist[17] = {0}; std::vector<long> lane_trips; std::vector<long> wave_trips; long bt = 0, subs = 0;
+  for (int t = 0; t < STEPS; t++) {
+    std::vector<long> tr(N);
+    for (int i = 0; i < N; i++) {
+      Stream<R> rng; rng.open(P.seed, P.gid_base + i, 0u);
+      Store<R> st{buf, 1}; int te, trn; float tob[6], rew;
+      stats() = Stats{};
+      env_step_mem<R, true, R>(P, st, rng, d.data(), f.data(), ii.data(), N, i, U(gen), U(gen), obs.data() + 6 * i, tob, rew, te, trn);
+      for (int k = 0; k < 17; k++) hist[k] += stats().hist[k];
+      bt += stats().backtracks[0]; subs += stats().substeps; tr[i] = stats().trips;
+      if (t >= 10) lane_trips.push_back(tr[i]);
+    }
+    if (t >= 10) for (int w = 0; w + 64 <= N; w += 64) wave_trips.push_back(*std::max_element(tr.begin() + w, tr.begin() + w + 64));
+  }
+  printf("substeps %ld backtracks %ld\niterations per substep:", subs, bt);
+  for (int k = 0; k < 17; k++) printf(" [%d]=%.5f", k, (double)hist[k] / subs);
+  std::sort(lane_trips.begin(), lane_trips.end()); std::sort(wave_trips.begin(), wave_trips.end());
+  auto q = [](std::vector<long>& v, double p) { return v[(size_t)(p * (v.size() - 1))]; };
+  double ml = 0; for (long x : lane_trips) ml += x; ml /= lane_trips.size();
+  double mw = 0; for (long x : wave_trips) mw += x; mw /= wave_trips.size();
+  printf("\nlane trips: mean %.1f p50 %ld p90 %ld p99 %ld p999 %ld max %ld\n", ml, q(lane_trips, .5), q(lane_trips, .9), q(lane_trips, .99), q(lane_trips, .999), lane_trips.back());
+  printf("wave trips: mean %.1f p50 %ld p90 %ld p99 %ld max %ld (n=%zu)\n", mw, q(wave_trips, .5), q(wave_trips, .9), q(wave_trips, .99), wave_trips.back(), wave_trips.size());
+  return 0;
+}

@@ -38,3 +38,16 @@ for k in range(20):
 import statistics as st_
 print(f"  slowest wave / mean wave: cycles x{st_.mean(r[0] for r in ratios):.3f}, trips x{st_.mean(r[1] for r in ratios):.3f} "
       f"(mean trips {st_.mean(r[2] for r in ratios):.1f}, max trips {st_.mean(r[3] for r in ratios):.1f})")
+
+# where did the slow waves of the last launch run?
+wb = (C.c_ulonglong * 4096)()
+L.brs_debug_waves(wb)
+import numpy as np
+w = np.array(list(wb), dtype=np.uint64).reshape(1024, 4)
+cyc, trips, hw, xcc = w[:, 0].astype(float), w[:, 1].astype(float), w[:, 2], w[:, 3] & 0xF
+cu = (hw >> 8) & 0xF; se = (hw >> 13) & 0x7; simd = (hw >> 4) & 0x3
+print(f"  last launch: cycles/trip mean {np.mean(cyc / trips):.0f} min {np.min(cyc / trips):.0f} max {np.max(cyc / trips):.0f}; corr(cycles, trips) {np.corrcoef(cyc, trips)[0, 1]:.2f}")
+for x in range(8):
+    m = xcc == x
+    if m.any(): print(f"    XCC {x}: waves {int(m.sum())} mean cycles {cyc[m].mean():.0f} max {cyc[m].max():.0f} cycles/trip {np.mean(cyc[m] / trips[m]):.0f}")
+np.save(os.path.join(ROOT, "gpurun_out", "wave_records.npy"), w)
