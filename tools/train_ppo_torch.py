@@ -205,9 +205,14 @@ def main():
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("BRS_PPO_ONE_DEVICE") == "1":   # rehearsal of N ranks on a one-GPU box (with BRS_PPO_BACKEND=gloo)
+        local = 0
     if world > 1:   # python -m torch.distributed.run --nproc-per-node N tools/train_ppo_torch.py ...: --envs is per rank
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if os.environ.get("BRS_PPO_BACKEND", "nccl") == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(os.environ["BRS_PPO_BACKEND"])
     torch.manual_seed(0)   # identical initial weights on every rank
     dev = torch.device("cuda", local)
     model = ActorCritic(a.log_std_init).to(dev)
