@@ -169,6 +169,49 @@ def test_closed_loop_statistics_under_pd_controller():
     sim.close(); orc.close()
 
 
+@pytest.mark.parametrize("env_id,n", [("Env03-v2", 1), ("Env03-v2", 100), ("Env01-v2", 65), ("Env03-v2", 257)])
+def test_ragged_batch_sizes(env_id, n):
+    """N that is not a multiple of the 64-lane wave (a partial last wave just masks lanes): reset + env steps vs the oracle"""
+    torch, sim, orc = _mk(env_id, n, seed=4, auto_reset=True, obs_noise=False)
+    np.testing.assert_allclose(sim.reset().cpu().numpy(), orc.reset(), atol=2e-5, rtol=1e-5)
+    rng = np.random.default_rng(2)
+    for t in range(12):
+        qpos, qvel, warm, tm = orc.get_state()
+        sim.set_state(qpos, qvel, warm, tm); sim.set_aux(orc.get_aux()); sim.set_xpose(*orc.get_xpose())
+        act = rng.uniform(-1, 1, size=(n, 2)).astype(np.float32)
+        out_g = [x.cpu().numpy().copy() for x in sim.step(torch.from_numpy(act).cuda())]
+        out_o = orc.step(act)
+        assert out_g[0].shape == (n, 6) and out_g[1].shape == (n,)
+        np.testing.assert_allclose(out_g[1], out_o[1], atol=1e-4, rtol=1e-5)
+        done = out_g[2].astype(bool) | out_g[3].astype(bool) | out_o[2] | out_o[3]
+        qg, qo = sim.get_state()[0], orc.get_state()[0]
+        assert np.abs(qg - qo)[~done].max(initial=0.0) < TOL_QPOS
+    sim.close(); orc.close()
+
+
+def test_masked_reset_touches_only_the_masked_envs():
+    """brs_reset with a device mask (include/brs.h): masked envs are re-drawn from their own streams exactly like the
+    oracle's, the others keep their state and their observation rows"""
+    n = 192
+    torch, sim, orc = _mk("Env03-v2", n, seed=9, auto_reset=False, obs_noise=False)
+    sim.reset(); orc.reset()
+    act = np.random.default_rng(3).uniform(-1, 1, size=(n, 2)).astype(np.float32)
+    for _ in range(3):
+        sim.step(torch.from_numpy(act).cuda()); orc.step(act)
+    qpos, qvel, warm, tm = orc.get_state()
+    sim.set_state(qpos, qvel, warm, tm); sim.set_aux(orc.get_aux()); sim.set_xpose(*orc.get_xpose())
+    q_before = sim.get_state()[0].copy()
+    mask = (np.arange(n) % 3 == 0)
+    og = sim.reset(torch.from_numpy(mask.astype(np.uint8))).cpu().numpy().copy()
+    oo = orc.reset(mask.astype(np.uint8))
+    qg, qo = sim.get_state()[0], orc.get_state()[0]
+    assert np.array_equal(qg[~mask], q_before[~mask]), "unmasked envs keep their state bit for bit"
+    np.testing.assert_allclose(qg[mask], qo[mask], atol=1e-6)
+    np.testing.assert_allclose(og[mask], oo[mask], atol=2e-5, rtol=1e-5)
+    assert np.abs(qg[mask] - q_before[mask]).max() > 1e-3, "masked envs did change"
+    sim.close(); orc.close()
+
+
 def test_full_size_properties():
     """BASELINE size (65,536 x Env03-v2): size-independent invariants after a random-policy rollout"""
     import torch
