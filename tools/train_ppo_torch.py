@@ -77,7 +77,7 @@ class MixedSim:
 
 
 def train(sim, model, opt, iters, n_steps, epochs, minibatch, gamma, lam, clip, log, tag, ent=0.0, reward_clip=None,
-          critic_warmup=0, lr_end=None, norm_returns=False):
+          critic_warmup=0, lr_end=None, norm_returns=False, target_kl=None):
     n = sim.n
     dev = sim.device
     obs = sim.reset().clone()
@@ -121,13 +121,23 @@ def train(sim, model, opt, iters, n_steps, epochs, minibatch, gamma, lam, clip, 
         flat = {k: v.reshape((-1,) + v.shape[2:]) for k, v in B.items()}
         fadv = adv.reshape(-1); fret = ret.reshape(-1)
         N = fadv.numel()
+        n_upd = 0; kl = 0.0; stop = False
         for _ in range(epochs):
+            if stop:
+                break
             perm = torch.randperm(N, device=dev)
             for s in range(0, N, minibatch):
                 idx = perm[s:s + minibatch]
                 d = model.dist(flat["obs"][idx])
                 logp = d.log_prob(flat["act"][idx]).sum(-1)
-                ratio = (logp - flat["logp"][idx]).exp()
+                lr_ = logp - flat["logp"][idx]
+                ratio = lr_.exp()
+                if target_kl is not None and it >= critic_warmup:   # SB3's target_kl: stop this iteration's updates when the
+                    with torch.no_grad():                            # policy has moved far enough from the one that sampled
+                        kl = float(_allreduce_mean_(((ratio - 1) - lr_).mean()))
+                    if kl > 1.5 * target_kl:
+                        stop = True
+                        break
                 a_ = fadv[idx]; a_ = (a_ - a_.mean()) / (a_.std() + 1e-8)
                 pl = -torch.min(ratio * a_, ratio.clamp(1 - clip, 1 + clip) * a_).mean()
                 vl = 0.5 * (model.v(flat["obs"][idx]).squeeze(-1) - fret[idx] / model.ret_scale).pow(2).mean()
@@ -138,7 +148,7 @@ def train(sim, model, opt, iters, n_steps, epochs, minibatch, gamma, lam, clip, 
                 opt.zero_grad(set_to_none=True); loss.backward(); allreduce_mean_grads(model)
                 # actor and critic are separate towers: clip them separately so large value targets cannot starve the actor
                 nn.utils.clip_grad_norm_(list(model.pi.parameters()) + [model.log_std], 0.5)
-                nn.utils.clip_grad_norm_(model.v.parameters(), 0.5); opt.step()
+                nn.utils.clip_grad_norm_(model.v.parameters(), 0.5); opt.step(); n_upd += 1
         total += n * n_steps * _world()
         if _world() > 1:
             st = torch.tensor([done_len_sum, done_ret_sum, done_cnt], dtype=torch.float64, device=dev)
@@ -146,7 +156,7 @@ def train(sim, model, opt, iters, n_steps, epochs, minibatch, gamma, lam, clip, 
         if done_cnt > 0:
             row = dict(tag=tag, iter=it, env_steps=total, wall_s=round(time.time() - t_start, 2),
                        mean_ep_len=done_len_sum / done_cnt, mean_ep_ret=done_ret_sum / done_cnt, episodes=int(done_cnt),
-                       log_std=round(float(model.log_std.detach().mean()), 3))
+                       log_std=round(float(model.log_std.detach().mean()), 3), updates=n_upd, kl=round(kl, 4))
             log.append(row)
             if (it % 10 == 0 or it == iters - 1) and (not dist.is_initialized() or dist.get_rank() == 0):
                 print(json.dumps(row), flush=True)
@@ -196,6 +206,8 @@ def main():
     ap.add_argument("--critic-warmup2", type=int, default=0, help="value-only iterations at the start of the second phase")
     ap.add_argument("--lr2-end", type=float, default=None, help="anneal the second phase's learning rate linearly to this")
     ap.add_argument("--norm-returns", action="store_true", help="critic in units of the running std of the returns")
+    ap.add_argument("--target-kl", type=float, default=None, help="stop an iteration's updates at 1.5x this approximate KL")
+    ap.add_argument("--seed", type=int, default=0, help="seeds the initial weights, the action noise and the env streams")
     ap.add_argument("--mix2", type=float, default=0.0, help="share of the envs kept in --env during the second phase")
     ap.add_argument("--reward-clip", type=float, default=None, help="learner-side upper clip of the per-step reward")
     ap.add_argument("--eval-steps", type=int, default=0, help="after training: deterministic evaluation for this many steps")
@@ -213,10 +225,10 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(os.environ["BRS_PPO_BACKEND"])
-    torch.manual_seed(0)   # identical initial weights on every rank
+    torch.manual_seed(a.seed)   # identical initial weights on every rank
     dev = torch.device("cuda", local)
     model = ActorCritic(a.log_std_init).to(dev)
-    torch.manual_seed(1000 + rank)   # ... different action noise
+    torch.manual_seed(1000 * (a.seed + 1) + rank)   # ... different action noise
     base = rank * a.envs
     opt = torch.optim.Adam(model.parameters(), lr=a.lr)
     log = []
@@ -236,13 +248,13 @@ def main():
                 model.log_std.requires_grad_(False)
         if phase == 1 and a.mix2 > 0:
             keep = int(a.envs * a.mix2) // 64 * 64
-            sim = MixedSim([BatchedSim(a.env, keep, device=local, seed=1, env_index_base=base, auto_reset=True),
-                            BatchedSim(env_id, a.envs - keep, device=local, seed=0, env_index_base=base, auto_reset=True)])
+            sim = MixedSim([BatchedSim(a.env, keep, device=local, seed=2 * a.seed + 1, env_index_base=base, auto_reset=True),
+                            BatchedSim(env_id, a.envs - keep, device=local, seed=2 * a.seed, env_index_base=base, auto_reset=True)])
             env_id = f"{a.env}+{env_id}"
         else:
-            sim = BatchedSim(env_id, a.envs, device=local, seed=0, env_index_base=base, auto_reset=True)
+            sim = BatchedSim(env_id, a.envs, device=local, seed=2 * a.seed, env_index_base=base, auto_reset=True)
         train(sim, model, opt, iters, a.n_steps, a.epochs, a.minibatch, a.gamma, a.lam, 0.2, log, env_id, a.ent, a.reward_clip,
-              warm, a.lr2_end if phase == 1 else None, a.norm_returns)
+              warm, a.lr2_end if phase == 1 else None, a.norm_returns, a.target_kl)
         sim.close()
     evals = []
     if world > 1:
