@@ -857,10 +857,12 @@ template <typename R, bool BLK> struct Sim {
       int mk = (e1 < 0 ? 1 : 0) | (e2 < 0 ? 2 : 0) | (e3 < 0 ? 4 : 0) | (e4 < 0 ? 8 : 0);
       // a row that sits on its own boundary (|e| below the rounding of its terms) carries no force either way:
       // its flip does not invalidate the quadratic piece H was built for
-      R tol = (R)BRS_FLIP_TOL * (abs_(cn) + abs_(c1) + abs_(c2));
       int df = mk ^ mh;
-      if (((df & 1) && abs_(e1) > tol) || ((df & 2) && abs_(e2) > tol) || ((df & 4) && abs_(e3) > tol) || ((df & 8) && abs_(e4) > tol))
-        sm = false;
+      if (df) {  // rare (a wave usually skips this block)
+        R tol = (R)BRS_FLIP_TOL * (abs_(cn) + abs_(c1) + abs_(c2));
+        if (((df & 1) && abs_(e1) > tol) || ((df & 2) && abs_(e2) > tol) || ((df & 4) && abs_(e3) > tol) || ((df & 8) && abs_(e4) > tol))
+          sm = false;
+      }
       return mk;
     }
 
