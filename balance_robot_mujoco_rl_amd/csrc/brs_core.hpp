@@ -112,8 +112,12 @@ BRS_HD bool isbad_(double x) { union { double f; uint64_t u; } c; c.f = x; retur
 template <typename R> BRS_HD R max_(R a, R b) { return a > b ? a : b; }
 template <typename R> BRS_HD R min_(R a, R b) { return a < b ? a : b; }
 
-template <typename R> BRS_HD R pick3(int k, R a, R b, R c) { return k == 0 ? a : (k == 1 ? b : c); }
-template <typename R> BRS_HD R pick3(int k, const R* v) { return k == 0 ? v[0] : (k == 1 ? v[1] : v[2]); }
+// three-way selects written as chains of two-way selects on VALUES: a nested ?: whose arms are loads is emitted as
+// control flow (exec-mask branches per use), this form as two v_cndmask
+template <typename R> BRS_HD R pick3(int k, R a, R b, R c) { R r = c; r = k == 1 ? b : r; r = k == 0 ? a : r; return r; }
+template <typename R> BRS_HD R pick3(int k, const R* v) { const R a = v[0], b = v[1], c = v[2]; return pick3<R>(k, a, b, c); }
+// value for body selector sel (0 torso, 1 left wheel, 2 right wheel): 0 / l / r
+template <typename R> BRS_HD R by_wheel(int sel, R l, R r) { R x = (R)0; x = sel == 1 ? l : x; x = sel == 2 ? r : x; return x; }
 template <typename R> BRS_HD void cross_(const R* a, const R* b, R* o) {
   R x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
   o[0] = x; o[1] = y; o[2] = z;
@@ -428,7 +432,7 @@ template <typename R, bool BLK> struct Sim {
 
   // wheel hinge column for a contact at r (torso frame) on wheel sel (1 L: axis -x at (-px,0,pz); 2 R: +x at (+px,0,pz))
   static BRS_HD void wheel_col(const Params<R>& P, int sel, const R* r, R* wc) {
-    R s = sel == 1 ? (R)-1 : (sel == 2 ? (R)1 : (R)0);
+    R s = by_wheel<R>(sel, (R)-1, (R)1);
     R dy = r[1], dz = r[2] - P.wheel_pz;
     wc[0] = 0; wc[1] = -s * dz; wc[2] = s * dy;  // (s e_x) x (d)
   }
@@ -443,7 +447,8 @@ template <typename R, bool BLK> struct Sim {
     R wc[3], wr[3];
     wheel_col(P, sel, r, wc);
     cross_(w, r, wr);
-    R wsel = sel == 1 ? ww[0] : (sel == 2 ? ww[1] : (R)0);
+    const R wwL = ww[0], wwR = ww[1];
+    R wsel = by_wheel<R>(sel, wwL, wwR);
     R pv[3] = {u[0] + wr[0] + wsel * wc[0], u[1] + wr[1] + wsel * wc[1], u[2] + wr[2] + wsel * wc[2]};
     R vn = dot_(F.nT(), pv), vt1 = dot_(F.t1T(), pv), vt2 = -dot_(F.xT(), pv);
     R imp = impedance_(c, dist);
@@ -558,7 +563,7 @@ template <typename R, bool BLK> struct Sim {
     R best = d0; int ax = 0;
     if (d1 > best) { best = d1; ax = 1; }
     if (d2 > best) { best = d2; ax = 2; }
-    R pv = ax == 0 ? p[0] : (ax == 1 ? p[1] : p[2]);
+    R pv = pick3<R>(ax, p);
     *axis = ax; *sign = pv >= 0 ? (R)1 : (R)-1;
     return best;
   }
@@ -585,7 +590,8 @@ template <typename R, bool BLK> struct Sim {
     wheel_col(P, sel, rT, wc);
     // relative point velocity (block minus robot), world frame
     cross_(S.w, rT, t);
-    R wsel = sel == 1 ? S.ww[0] : (sel == 2 ? S.ww[1] : (R)0);
+    const R wwL = S.ww[0], wwR = S.ww[1];
+    R wsel = by_wheel<R>(sel, wwL, wwR);
     R pT[3] = {t[0] + wsel * wc[0], t[1] + wsel * wc[1], t[2] + wsel * wc[2]}, pTw[3], pBw[3];
     mul_(F.RT, pT, pTw);
     cross_(S.bw, rB, t);
@@ -675,10 +681,10 @@ template <typename R, bool BLK> struct Sim {
             mul_(RTB, loc, p);
             p[0] += cg[0]; p[1] += cg[1]; p[2] += cg[2];
             R dist = sg * pick3(k, p) - sTk;
-            bool lat = true;
+            bool lat = true;  // (bitwise on purpose: && / || chains become exec-mask branches)
 #pragma unroll
-            for (int i = 0; i < 3; i++) lat = lat && (i == k || abs_(p[i]) <= sT[i] + c.margin);
-            cval[v] = dist < c.margin && lat;
+            for (int i = 0; i < 3; i++) lat = lat & ((i == k) | (abs_(p[i]) <= sT[i] + c.margin));
+            cval[v] = (dist < c.margin) & lat;
             cdist[v] = dist;
 #pragma unroll
             for (int i = 0; i < 3; i++) cpos[v][i] = p[i] - nrm[i] * dist * (R)0.5;
@@ -710,8 +716,8 @@ template <typename R, bool BLK> struct Sim {
             R dist = -sgB * pick3(j, pB) - s;
             bool lat = true;
 #pragma unroll
-            for (int i = 0; i < 3; i++) lat = lat && (i == j || abs_(pB[i]) <= s + c.margin);
-            cval[v] = dist < c.margin && lat;
+            for (int i = 0; i < 3; i++) lat = lat & ((i == j) | (abs_(pB[i]) <= s + c.margin));
+            cval[v] = (dist < c.margin) & lat;
             cdist[v] = dist;
 #pragma unroll
             for (int i = 0; i < 3; i++) cpos[v][i] = loc[i] + nrm[i] * dist * (R)0.5;
@@ -887,7 +893,8 @@ template <typename R, bool BLK> struct Sim {
         R wc[3], t[3];
         wheel_col(P, sel, r, wc);
         cross_(x + 3, r, t);
-        R xs = sel == 1 ? x[6] : (sel == 2 ? x[7] : (R)0);
+        const R x6 = x[6], x7 = x[7];
+        R xs = by_wheel<R>(sel, x6, x7);
         R pa[3] = {x[0] + t[0] + xs * wc[0], x[1] + t[1] + xs * wc[1], x[2] + t[2] + xs * wc[2]};
         int mk = rows_(dot_(F.nT(), pa) - An, mu * dot_(F.t1T(), pa) - Bt1, -mu * dot_(F.xT(), pa) - Bt2, D, cst, l, get4(M.hR, c), sm);
         M.nR |= put4(mk, c);
@@ -928,7 +935,8 @@ template <typename R, bool BLK> struct Sim {
           coupled_load(P, st, F, c, C);
           R t[3];
           cross_(x + 3, C.rT, t);
-          R xs = C.sel == 1 ? x[6] : (C.sel == 2 ? x[7] : (R)0);
+          const R x6 = x[6], x7 = x[7];
+          R xs = by_wheel<R>(C.sel, x6, x7);
           R paT[3] = {x[0] + t[0] + xs * C.wc[0], x[1] + t[1] + xs * C.wc[1], x[2] + t[2] + xs * C.wc[2]};
           cross_(x + 11, C.rB, t);
           R paB[3] = {x[8] + t[0], x[9] + t[1], x[10] + t[2]};
