@@ -660,7 +660,7 @@ template <typename R, bool BLK> struct Sim {
         // candidates of the incident face first (cheap, case-specific), insertion afterwards in ONE uniform loop
         R cpos[4][3], cdist[4], nrm[3];
         bool cval[4];
-        R fb_dist = (R)1e30, fb_pos[3] = {0, 0, 0};
+        R fb_dist = (R)1e30, fbp[3] = {0, 0, 0};
         if (bestax < 3) {
           const int k = bestax;
           R sg = pick3(k, cg) >= 0 ? (R)1 : (R)-1;
@@ -688,11 +688,10 @@ template <typename R, bool BLK> struct Sim {
             cdist[v] = dist;
 #pragma unroll
             for (int i = 0; i < 3; i++) cpos[v][i] = p[i] - nrm[i] * dist * (R)0.5;
-            if (dist < fb_dist) {
-              fb_dist = dist;
+            const bool deeper = dist < fb_dist;  // deepest incident vertex (its clamped position is only needed in the
+            fb_dist = deeper ? dist : fb_dist;   // rare no-vertex-inside case below)
 #pragma unroll
-              for (int i = 0; i < 3; i++) fb_pos[i] = (i == k ? p[i] : max_(-sT[i], min_(sT[i], p[i]))) - nrm[i] * dist * (R)0.5;
-            }
+            for (int i = 0; i < 3; i++) fbp[i] = deeper ? p[i] : fbp[i];
           }
         } else {
           const int j = bestax - 3;
@@ -721,23 +720,27 @@ template <typename R, bool BLK> struct Sim {
             cdist[v] = dist;
 #pragma unroll
             for (int i = 0; i < 3; i++) cpos[v][i] = loc[i] + nrm[i] * dist * (R)0.5;
-            if (dist < fb_dist) {
-              R q[3], back[3];
+            const bool deeper = dist < fb_dist;
+            fb_dist = deeper ? dist : fb_dist;
 #pragma unroll
-              for (int i = 0; i < 3; i++) q[i] = i == j ? pB[i] : max_(-s, min_(s, pB[i]));
-              mul_(RTB, q, back);
-              fb_dist = dist;
-#pragma unroll
-              for (int i = 0; i < 3; i++) fb_pos[i] = back[i] + cg[i] + nrm[i] * dist * (R)0.5;
-            }
+            for (int i = 0; i < 3; i++) fbp[i] = deeper ? pB[i] : fbp[i];
           }
         }
-        if (!(cval[0] || cval[1] || cval[2] || cval[3]) && fb_dist < c.margin) {  // no vertex inside the rectangle: clamped deepest one
+        if (!(cval[0] | cval[1] | cval[2] | cval[3]) & (fb_dist < c.margin)) {  // no vertex inside the rectangle: clamped deepest one
           cval[0] = true; cdist[0] = fb_dist;
+          if (bestax < 3) {  // fbp in the torso geom frame: clamp into the reference rectangle
 #pragma unroll
-          for (int i = 0; i < 3; i++) cpos[0][i] = fb_pos[i];
+            for (int i = 0; i < 3; i++) cpos[0][i] = (i == bestax ? fbp[i] : max_(-sT[i], min_(sT[i], fbp[i]))) - nrm[i] * fb_dist * (R)0.5;
+          } else {           // fbp in the block frame: clamp there, map back
+            R q[3], back[3];
+#pragma unroll
+            for (int i = 0; i < 3; i++) q[i] = i == bestax - 3 ? fbp[i] : max_(-s, min_(s, fbp[i]));
+            mul_(RTB, q, back);
+#pragma unroll
+            for (int i = 0; i < 3; i++) cpos[0][i] = back[i] + cg[i] + nrm[i] * fb_dist * (R)0.5;
+          }
         }
-        if (cval[0] || cval[1] || cval[2] || cval[3]) {
+        if (cval[0] | cval[1] | cval[2] | cval[3]) {
           R fw[9];
           world_frame(F, nrm, fw);  // one contact frame for the whole patch
           bool first_in_patch = true;
@@ -768,19 +771,18 @@ template <typename R, bool BLK> struct Sim {
         R loc[3] = {(i & 1) ? s : -s, (i & 2) ? s : -s, (i & 4) ? s : -s}, v[3];
         mul_(RTB, loc, v);
         R p[3] = {v[0] + d[0], v[1] + d[1], v[2] + d[2]};  // vertex relative to the wheel centre; axis = x
+        // branch-free on purpose: 8 vertices x 2 wheels of two-sided branches cost more than the selects
         R xi = p[0], rho = sqrt_(p[1] * p[1] + p[2] * p[2]);
-        R drad = rho - P.wheel_r, dax = abs_(xi) - P.wheel_hl, dist, nrm[3];
-        bool ok = true;
-        if (drad >= dax) {
-          if (rho < (R)1e-9) ok = false;
-          R ir = rcp_(max_(rho, (R)1e-9));
-          dist = drad; nrm[0] = 0; nrm[1] = p[1] * ir; nrm[2] = p[2] * ir;
-        } else { dist = dax; nrm[0] = xi >= 0 ? (R)1 : (R)-1; nrm[1] = 0; nrm[2] = 0; }
-        if (ok && dist < best) {
-          best = dist; found = true;
+        R drad = rho - P.wheel_r, dax = abs_(xi) - P.wheel_hl;
+        const bool radial = drad >= dax;
+        const R ir = rcp_(max_(rho, (R)1e-9));
+        const R dist = radial ? drad : dax;
+        const R nrm[3] = {radial ? (R)0 : (xi >= 0 ? (R)1 : (R)-1), radial ? p[1] * ir : (R)0, radial ? p[2] * ir : (R)0};
+        const bool take = (!radial | (rho >= (R)1e-9)) & (dist < best);
+        best = take ? dist : best;
+        found = found | take;
 #pragma unroll
-          for (int j = 0; j < 3; j++) { bn[j] = nrm[j]; bpos[j] = p[j] + wp[j] - nrm[j] * dist * (R)0.5; }
-        }
+        for (int j = 0; j < 3; j++) { bn[j] = take ? nrm[j] : bn[j]; bpos[j] = take ? p[j] + wp[j] - nrm[j] * dist * (R)0.5 : bpos[j]; }
       }
       R xid = d[0], rho = sqrt_(d[1] * d[1] + d[2] * d[2]);
       if (rho > (R)1e-9) {
