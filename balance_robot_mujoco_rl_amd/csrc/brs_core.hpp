@@ -253,7 +253,8 @@ template <typename R> BRS_HD R impedance_(const ContactClass<R>& c, R dist) {
   if (c.inv_width == (R)0) return c.d0;
   R x = (c.margin - dist) * c.inv_width;  // >= 0 for an active contact
   x = min_(x, (R)1);
-  R y = x <= (R)0.5 ? 2 * x * x : 1 - 2 * (1 - x) * (1 - x);
+  const R om = 1 - x, lo = 2 * x * x, hi = 1 - 2 * om * om;  // both arms as values: a select, not a two-sided branch
+  const R y = x <= (R)0.5 ? lo : hi;
   return c.d0 + y * (c.d1 - c.d0);
 }
 
