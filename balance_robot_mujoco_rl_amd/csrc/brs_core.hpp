@@ -797,10 +797,14 @@ template <typename R, bool BLK> struct Sim {
           mulT_(RTB, rel, p);
           int ax; R sg;
           R dist = point_box(p, s, s, s, &ax, &sg);
-          if (dist < best) {
-            best = dist; found = true;
+          const bool take = dist < best;  // (selects: see the vertex loop)
+          best = take ? dist : best;
+          found = found | take;
 #pragma unroll
-            for (int j = 0; j < 3; j++) { bn[j] = -sg * RTB[3 * j + ax]; bpos[j] = q[j] + wp[j] + bn[j] * dist * (R)0.5; }
+          for (int j = 0; j < 3; j++) {
+            const R nj = -sg * pick3<R>(ax, RTB[3 * j], RTB[3 * j + 1], RTB[3 * j + 2]);
+            bn[j] = take ? nj : bn[j];
+            bpos[j] = take ? q[j] + wp[j] + nj * dist * (R)0.5 : bpos[j];
           }
         }
       }
