@@ -96,9 +96,14 @@ class BalanceVecEnv(_VecEnvBase):
             self._sims = [BatchedSim(env_id, cnt, device=dev, seed=seed, env_index_base=env_index_base + start,
                                      auto_reset=True, obs_noise=obs_noise, max_episode_steps=max_episode_steps)
                           for dev, (start, cnt) in zip(devices, shard_ranges(num_envs, len(devices)))]
+            # a device listed more than once (devices=[0, 0]) gets one handle per entry, each on its own stream, so that
+            # the shards' kernels overlap on that GPU; a device listed once uses the current stream
+            repeated = {d for d in devices if list(devices).count(d) > 1}
+            self._streams = [torch.cuda.Stream(torch.device("cuda", d)) if d in repeated else None for d in devices][:len(self._sims)]
         else:  # tests inject stand-ins with the same surface
             self._torch = None
             self._sims = list(_sims)
+            self._streams = [None] * len(self._sims)
         self._ranges = []
         start = 0
         for s in self._sims:
@@ -117,12 +122,25 @@ class BalanceVecEnv(_VecEnvBase):
     def _to_numpy(self, t):
         return t.detach().cpu().numpy() if hasattr(t, "detach") else np.asarray(t)
 
+    def _sync_streams(self):
+        for st in self._streams:
+            if st is not None:
+                st.synchronize()
+
     def _gather(self, parts):
         return parts[0] if len(parts) == 1 else np.concatenate(parts, axis=0)
 
     # ------------------------------------------------------------------ VecEnv API
     def reset(self):
-        obs = self._gather([self._to_numpy(s.reset()).copy() for s in self._sims])
+        outs = []
+        for s, st in zip(self._sims, self._streams):
+            if st is None:
+                outs.append(s.reset())
+            else:
+                with self._torch.cuda.stream(st):
+                    outs.append(s.reset())
+        self._sync_streams()
+        obs = self._gather([self._to_numpy(o).copy() for o in outs])
         self._ep_ret[:] = 0
         self._ep_len[:] = 0
         self.reset_infos = [{} for _ in range(self.num_envs)]
@@ -131,10 +149,15 @@ class BalanceVecEnv(_VecEnvBase):
     def step_async(self, actions):
         a = np.asarray(actions, dtype=np.float32).reshape(self.num_envs, 2)
         self._pending = []
-        for s, (start, cnt) in zip(self._sims, self._ranges):  # enqueue on every device before waiting on any
-            self._pending.append(s.step(a[start:start + cnt]))
+        for s, st, (start, cnt) in zip(self._sims, self._streams, self._ranges):  # enqueue on every device before waiting on any
+            if st is None:
+                self._pending.append(s.step(a[start:start + cnt]))
+            else:
+                with self._torch.cuda.stream(st):
+                    self._pending.append(s.step(a[start:start + cnt]))
 
     def step_wait(self):
+        self._sync_streams()
         obs, rew, term, trunc, tob = ([] for _ in range(5))
         for out in self._pending:
             o, r, te, tr, to = out
@@ -214,7 +237,8 @@ class BalanceVectorEnv:
     def step(self, actions):
         a = np.asarray(actions, dtype=np.float32).reshape(self.num_envs, 2)
         v = self._v
-        v._pending = [s.step(a[st:st + cnt]) for s, (st, cnt) in zip(v._sims, v._ranges)]
+        v.step_async(a)
+        v._sync_streams()
         obs, rew, term, trunc, tob = ([] for _ in range(5))
         for o, r, te, tr, to in v._pending:
             obs.append(v._to_numpy(o).copy()); rew.append(v._to_numpy(r).copy())
