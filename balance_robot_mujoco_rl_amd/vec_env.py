@@ -100,6 +100,8 @@ class BalanceVecEnv(_VecEnvBase):
             # the shards' kernels overlap on that GPU; a device listed once uses the current stream
             repeated = {d for d in devices if list(devices).count(d) > 1}
             self._streams = [torch.cuda.Stream(torch.device("cuda", d)) if d in repeated else None for d in devices][:len(self._sims)]
+            for d in repeated:  # the handles' buffers were zero-filled on the default stream: finish that first
+                torch.cuda.synchronize(torch.device("cuda", d))
         else:  # tests inject stand-ins with the same surface
             self._torch = None
             self._sims = list(_sims)
