@@ -131,3 +131,35 @@ def test_no_contacts_when_apart_and_some_when_overlapping():
         inside = TORSO_C + rng.uniform(-0.6, 0.6, 3) * TORSO_S   # block centre well inside the torso box
         hits += bool(_contacts(o, inside, _quat(rng)))
     assert hits == 100
+
+
+def test_floor_contacts_of_wheels_and_torso_are_surface_points():
+    """plane<->cylinder / plane<->box restated from MuJoCo's primitives (oracle plane_cylinder / plane_box): every contact
+    has the plane normal, its point is half a distance below a point ON the geom surface, and that surface point is
+    `dist` above the floor (z = -0.02, ref:envs/env01_v1.xml:27)"""
+    rng = np.random.default_rng(9)
+    o = O.Oracle("Env01-v2", 1)
+    FLOOR = -0.02
+    seen = {1: 0, 2: 0, 3: 0}
+    for _ in range(300):
+        q = np.zeros((1, 9)); bq = _quat(rng); R = _rot(bq)
+        q[0, 3:7] = bq
+        # lowest point of the robot's geoms just touching the floor (+- 3 mm)
+        pts = [TORSO_C + np.array([sx, sy, sz]) * TORSO_S for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)]
+        low = min((R @ p)[2] for p in pts)
+        for w in (2, 3):
+            for th in np.linspace(0, 2 * np.pi, 64, endpoint=False):
+                for ax in (-WHEEL_HL, WHEEL_HL):
+                    low = min(low, (R @ (WHEEL_P[w] + np.array([ax, WHEEL_R * np.cos(th), WHEEL_R * np.sin(th)])))[2])
+        q[0, 2] = FLOOR - low + rng.uniform(-0.003, 0.001)
+        o.set_state(q, np.zeros((1, 8)))
+        for con in o.forward()["contacts"]:
+            assert con["body1"] == 0 and con["body2"] in (1, 2, 3)
+            np.testing.assert_allclose(con["frame"][0], [0, 0, 1], atol=1e-12)
+            surf_w = con["pos"] + con["frame"][0] * con["dist"] * 0.5          # world point on the geom surface
+            assert abs((surf_w[2] - FLOOR) - con["dist"]) < 1e-9
+            p_body = R.T @ (surf_w - q[0, :3])
+            sd = _sd_box(p_body - TORSO_C, TORSO_S) if con["body2"] == 1 else _sd_cyl_x(p_body - WHEEL_P[con["body2"]], WHEEL_R, WHEEL_HL)
+            assert abs(sd) < 1e-9, (con["body2"], sd)
+            seen[con["body2"]] += 1
+    assert min(seen.values()) > 20, seen
