@@ -174,3 +174,27 @@ def test_block_rests_on_floor_and_is_detected():
     f = o.forward()
     assert sum(1 for c in f["contacts"] if c["body2"] == 4 and c["body1"] == 0) == 4
     assert abs(vv[0, 10]) < 1e-3 and -0.002 < qq[0, 11] - 0.0 < 0.002  # centre ~ floor_z + half size = 0, inside the margin band
+
+
+def test_solver_stationarity_on_random_contact_states():
+    """the Newton solution is a stationary point of the convex acceleration problem: M (qacc - qacc_smooth) equals the
+    constraint force J^T f it reports, and the pyramidal row forces are non-negative (states from a random rollout with
+    wheel, torso, block<->floor and block<->robot contacts)"""
+    o = O.Oracle("Env03-v2", 24, seed=5, noise=False, auto_reset=False, threads=8)
+    o.reset()
+    rng = np.random.default_rng(0)
+    checked = with_coupled = 0
+    for t in range(40):
+        o.step(rng.uniform(-1, 1, size=(24, 2)).astype(np.float32))
+        qv = o.get_state()[1]
+        for e in range(0, 24, 3):
+            f = o.forward(env=e, ctrl=(qv[e, 6], qv[e, 7]))
+            if f["ncon"] == 0:
+                continue
+            lhs = f["M"] @ (f["qacc"] - f["qacc_smooth"])
+            scale = max(1e-9, np.abs(f["qfrc_constraint"]).max())
+            assert np.abs(lhs - f["qfrc_constraint"]).max() < 1e-6 * scale + 1e-10, (t, e)
+            assert (f["efc_force"] >= -1e-12).all()
+            checked += 1
+            with_coupled += any(c["body2"] == 4 and c["body1"] != 0 for c in f["contacts"])
+    assert checked > 100 and with_coupled > 0
