@@ -67,3 +67,14 @@ def test_product_never_imports_oracle():
                 t = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in t and "from oracle" not in t and "libbrs_oracle" not in t, f
                 assert "libbrs_hostsim" not in t, f
+
+
+def test_tools_and_entry_points_compile():
+    """every script under tools/ and the driver entry points are at least syntactically valid Python (most of them only
+    run on a GPU box)"""
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = glob.glob(os.path.join(root, "tools", "*.py")) + [os.path.join(root, f) for f in ("bench.py", "__graft_entry__.py")]
+    assert len(files) >= 8
+    for f in files:
+        compile(open(f).read(), f, "exec")
