@@ -60,3 +60,40 @@ def test_free_run_env_steps_match_with_shared_rng():
         np.testing.assert_allclose(ro, rh, atol=1e-5)
         assert np.array_equal(teo, teh) and np.array_equal(tro, trh)
         assert np.array_equal(o.get_aux()[:, 2:5], h.get_aux()[:, 2:5])
+
+
+@pytest.mark.parametrize("double,tol", [(True, 1e-12), (False, 1e-5)])
+def test_constructed_block_robot_contact_states(double, tol):
+    """block placed (random pose, random approach velocity) against the torso faces and the wheels of an airborne robot:
+    the kernel source and the oracle must generate the same contacts and the same impulses over 5 substeps -- the coupled
+    path on far more configurations than a rollout visits"""
+    rng = np.random.default_rng(17)
+    n = 96
+    TC, TS, BS = np.array([0.0, 0.0, 0.0995]), np.array([0.05, 0.0185, 0.0855]), 0.02
+    WP = {1: np.array([-0.074, 0.0, 0.034]), 2: np.array([0.074, 0.0, 0.034])}
+    qpos = np.zeros((n, 16)); qvel = np.zeros((n, 14))
+    qpos[:, 3] = 1.0; qpos[:, 2] = 1.0                      # robot 1 m up: no floor contacts
+    for i in range(n):
+        if i % 3 == 0:
+            face = rng.integers(3); sign = rng.choice([-1.0, 1.0])
+            c = TC + rng.uniform(-1, 1, 3) * TS
+            c[face] = TC[face] + sign * (TS[face] + BS * rng.uniform(0.7, 1.3))
+        else:
+            th = rng.uniform(0, 2 * np.pi); rad = 0.034 + BS * rng.uniform(0.7, 1.3)
+            c = WP[1 + i % 2] + np.array([rng.uniform(-1, 1) * 0.013, rad * np.cos(th), rad * np.sin(th)])
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        qpos[i, 9:12] = c + np.array([0, 0, 1.0]); qpos[i, 12:16] = q
+        qvel[i, 8:11] = rng.normal(size=3) * 2.0             # block linear velocity (m/s), spin
+        qvel[i, 11:14] = rng.normal(size=3) * 5.0
+        qvel[i, 6:8] = rng.normal(size=2) * 10.0             # wheels spinning
+    o = O.Oracle("Env03-v2", n, noise=False, threads=8)
+    h = HostSim("Env03-v2", n, noise=False, double=double)
+    o.set_state(qpos, qvel); h.set_state(qpos, qvel)
+    ctrl = np.zeros((n, 2))
+    o.physics(ctrl, 5); h.physics(ctrl, 5)
+    (qo, vo, _, _), (qh, vh, _, _) = o.get_state(), h.get_state()
+    touched = np.abs(vo[:, :6]).max(axis=1) > 1e-6          # the robot was pushed: a coupled contact acted
+    assert touched.sum() > n // 3
+    scale = 1.0 + np.abs(vo).max(axis=1)
+    err = np.abs(vo - vh).max(axis=1) / scale
+    assert np.quantile(err, 0.98) < tol and err.max() < 50 * tol, (np.quantile(err, 0.98), err.max())
