@@ -97,3 +97,48 @@ def test_constructed_block_robot_contact_states(double, tol):
     scale = 1.0 + np.abs(vo).max(axis=1)
     err = np.abs(vo - vh).max(axis=1) / scale
     assert np.quantile(err, 0.98) < tol and err.max() < 50 * tol, (np.quantile(err, 0.98), err.max())
+
+
+@pytest.mark.parametrize("double,tol", [(True, 1e-12), (False, 5e-6)])
+def test_constructed_floor_contact_states(double, tol):
+    """robot in random orientations (upright, on a wheel's side, on the torso, upside down) pressed 0..3 mm into the floor
+    with random velocities: wheel rim / side / triangle points and torso corners, up to the 8-slot capacity"""
+    rng = np.random.default_rng(23)
+    n = 128
+    TC, TS = np.array([0.0, 0.0, 0.0995]), np.array([0.05, 0.0185, 0.0855])
+    WP = [np.array([-0.074, 0.0, 0.034]), np.array([0.074, 0.0, 0.034])]
+    pts = [TC + np.array([sx, sy, sz]) * TS for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)]
+    for w in WP:
+        for th in np.linspace(0, 2 * np.pi, 48, endpoint=False):
+            for ax in (-0.013, 0.013):
+                pts.append(w + np.array([ax, 0.034 * np.cos(th), 0.034 * np.sin(th)]))
+    pts = np.array(pts)
+    qpos = np.zeros((n, 9)); qvel = np.zeros((n, 8))
+    for i in range(n):
+        q = rng.normal(size=4)
+        if i % 4 == 0:
+            q = np.array([1.0, 0, 0, 0]) + 0.05 * rng.normal(size=4)     # near upright
+        elif i % 4 == 1:                                                  # lying on the torso's broad face (+-90 deg about x)
+            a = rng.choice([-1.0, 1.0]) * (np.pi / 2 + 0.02 * rng.normal())
+            q = np.array([np.cos(a / 2), np.sin(a / 2), 0, 0]) + 0.004 * rng.normal(size=4)
+        elif i % 4 == 2:                                                  # on a wheel's flat side (+-90 deg about y)
+            a = rng.choice([-1.0, 1.0]) * (np.pi / 2 + 0.02 * rng.normal())
+            q = np.array([np.cos(a / 2), 0, np.sin(a / 2), 0]) + 0.004 * rng.normal(size=4)
+        q /= np.linalg.norm(q)
+        w_, x, y, z = q
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w_ * z), 2 * (x * z + w_ * y)],
+                      [2 * (x * y + w_ * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w_ * x)],
+                      [2 * (x * z - w_ * y), 2 * (y * z + w_ * x), 1 - 2 * (x * x + y * y)]])
+        low = (pts @ R.T)[:, 2].min()
+        qpos[i, 3:7] = q; qpos[i, 2] = -0.02 - low - rng.uniform(0.0, 0.003 if i % 4 in (0, 3) else 0.015)   # flat poses pressed deeper: more points
+        qvel[i, :3] = rng.normal(size=3) * 0.3; qvel[i, 3:6] = rng.normal(size=3) * 2.0; qvel[i, 6:8] = rng.normal(size=2) * 15.0
+    o = O.Oracle("Env01-v2", n, noise=False, threads=8)
+    h = HostSim("Env01-v2", n, noise=False, double=double)
+    o.set_state(qpos, qvel); h.set_state(qpos, qvel)
+    ncon = np.array([o.forward(env=i)["ncon"] for i in range(n)])
+    assert ncon.min() >= 1 and ncon.max() >= 6, (ncon.min(), ncon.max())
+    ctrl = rng.uniform(-30, 30, size=(n, 2))
+    o.physics(ctrl, 5); h.physics(ctrl, 5)
+    vo, vh = o.get_state()[1], h.get_state()[1]
+    err = np.abs(vo - vh).max(axis=1) / (1.0 + np.abs(vo).max(axis=1))
+    assert np.quantile(err, 0.98) < tol and err.max() < 50 * tol, (np.quantile(err, 0.98), err.max())
