@@ -4,7 +4,7 @@
 MuJoCo is not installed in the build container nor on the GPU box and cannot be installed (no network); this script
 then prints "oracle unavailable: mujoco is not importable" and exits 3.  It is the tool that closes SURVEY.md App. C's
 [VERIFY] list on the first machine that has MuJoCo 3.2.0 (the reference's pin, conda-environment.yaml:7).  It loads OUR
-re-typed XML (balance_robot_mujoco_rl_amd/assets/), never the reference's files.
+re-typed XML (tools/mujoco_assets/), never the reference's files.
 
     python tools/mujoco_compare.py [--env Env01-v2] [--envs 16] [--steps 200] [--gpu]
 """
@@ -26,7 +26,7 @@ def main():
         return 3
     from oracle import oracle as O
     fam = "env01" if a.env.startswith("Env01") else "env03"
-    m = mujoco.MjModel.from_xml_path(os.path.join(ROOT, "balance_robot_mujoco_rl_amd", "assets", fam + ".xml"))
+    m = mujoco.MjModel.from_xml_path(os.path.join(ROOT, "tools", "mujoco_assets", fam + ".xml"))
     orc = O.Oracle(a.env, a.envs, seed=0, auto_reset=False, noise=False)
     mi = orc.model_info()
     rep = {"mujoco_version": mujoco.__version__,
