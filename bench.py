@@ -25,7 +25,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X spec (MI355X_MICROARCH.md chip table; 6.29
 FP32_VALU_PEAK_TFLOPS = 157.3
 
 
-def cpu_baseline(env_id, seconds_budget=20.0):
+def cpu_baseline(env_id, seconds_budget=12.0):
     """oracle/ ("port": this repo's fp64 CPU restatement, NOT MuJoCo -- MuJoCo is not installable here) timed on
     the host cores on a bounded sample of the same workload"""
     from oracle import oracle as O
@@ -34,8 +34,8 @@ def cpu_baseline(env_id, seconds_budget=20.0):
     orc = O.Oracle(env_id, n, seed=0, auto_reset=True, threads=cores)
     orc.reset()
     rng = np.random.default_rng(1234)
-    act = rng.uniform(-1, 1, size=(n, 2)).astype(np.float32)
-    orc.step(act)  # warm-up
+    for _ in range(40):  # past the 2 cm drop that starts every episode: wheels on the floor, first blocks arriving
+        orc.step(rng.uniform(-1, 1, size=(n, 2)).astype(np.float32))
     t0 = time.perf_counter()
     steps = 0
     while True:
@@ -45,8 +45,60 @@ def cpu_baseline(env_id, seconds_budget=20.0):
         if el > seconds_budget or steps >= 400:
             break
     return {"value": n * steps / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{env_id}, {n} envs x {steps} steps, random actions, auto-reset, oracle/brs_oracle.c fp64 "
-                      f"with OpenMP over envs ({el:.1f} s); own CPU restatement, not MuJoCo"}
+            "us_per_substep_per_core": el * cores / (n * steps * 250) * 1e6,
+            "sample": f"{env_id}, {n} envs x {steps} steps after 40 untimed, random actions, auto-reset, "
+                      f"oracle/brs_oracle.c fp64 (general body tree, numeric Jacobians, MuJoCo-style Newton) with "
+                      f"OpenMP over envs ({el:.1f} s); own CPU restatement, not MuJoCo"}
+
+
+def cpu_baseline_closed_form(env_id, seconds_budget=10.0):
+    """second CPU figure: the kernel's own source (closed-form gyrostat dynamics, active-set Newton) compiled for the
+    host in double with OpenMP over envs (tests/hostsim -- test infrastructure, timed only here).  SURVEY.md section 6
+    estimates MuJoCo itself at 2-6 us per substep per core on this model."""
+    from tests.hostsim.hostsim import HostSim
+    cores = min(os.cpu_count() or 1, 64)
+    n = 32 * cores
+    hs = HostSim(env_id, n, seed=0, auto_reset=True, double=True, threads=cores)
+    hs.reset()
+    rng = np.random.default_rng(1234)
+    for _ in range(40):
+        hs.step(rng.uniform(-1, 1, size=(n, 2)).astype(np.float32))
+    t0 = time.perf_counter()
+    steps = 0
+    while True:
+        hs.step(rng.uniform(-1, 1, size=(n, 2)).astype(np.float32))
+        steps += 1
+        el = time.perf_counter() - t0
+        if el > seconds_budget or steps >= 2000:
+            break
+    return {"value": n * steps / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "us_per_substep_per_core": el * cores / (n * steps * 250) * 1e6,
+            "sample": f"{env_id}, {n} envs x {steps} steps after 40 untimed, random actions, auto-reset, host build of "
+                      f"the kernel source in fp64 (tests/hostsim) with OpenMP over envs ({el:.1f} s); not MuJoCo"}
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start torch.distributed.run as a CHILD before anything here has
+    touched the GPU (a process that initialised HIP must never exec), relay rank 0's JSON line and exit code"""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line)
+    return proc.returncode if line is not None or proc.returncode else 1
 
 
 def main():
@@ -57,10 +109,20 @@ def main():
     ap.add_argument("--envs", type=int, default=65536, help="env instances per GPU")
     ap.add_argument("--env", default="Env03-v2")
     ap.add_argument("--block-threads", type=int, default=0)
+    ap.add_argument("--preroll", type=int, default=300,
+                    help="minimum untimed env steps after reset(), on top of --warmup: all episodes start in phase (2 cm "
+                         "drop, no contacts, first block in flight); the pre-roll runs until falls and auto-resets have "
+                         "de-phased them and the per-step kernel time is stationary")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
+    world = int(env_world or "1")
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with --nproc-per-node {args.gpus}", file=sys.stderr)
+        sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
@@ -102,15 +164,32 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for k in range(args.warmup):
-        sim.step(actions[k % pool])
+    # ---- untimed pre-roll to steady state (independent of --warmup): windows of 50 steps, HIP-event time per window;
+    # stop once `--preroll` steps are done AND two consecutive windows agree within 2 %, or at the cap
+    kstep = 0
+    win, cap = 50, max(args.preroll, 1500)
+    win_ms = []
+    while True:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(win):
+            sim.step(actions[kstep % pool]); kstep += 1
+        e1.record()
+        e1.synchronize()
+        win_ms.append(e0.elapsed_time(e1) / win)
+        stationary = len(win_ms) >= 2 and abs(win_ms[-1] - win_ms[-2]) <= 0.02 * win_ms[-2]
+        if (kstep >= args.preroll and stationary) or kstep >= cap:
+            break
+    preroll = kstep
+    for _ in range(args.warmup):
+        sim.step(actions[kstep % pool]); kstep += 1
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
         ev0[k].record()
-        sim.step(actions[k % pool])
+        sim.step(actions[kstep % pool]); kstep += 1
         ev1[k].record()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -118,7 +197,9 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))  # HIP events on the launch stream
+    # HIP events on the stream the kernel is launched on (BatchedSim launches on torch's current stream)
+    kms = np.array([a.elapsed_time(b) for a, b in zip(ev0, ev1)])
+    kern_ms = float(kms.mean())
     n_done = int(sim.terminated.sum().item())  # touches the outputs (also proves the last step ran)
 
     if rank == 0:
@@ -132,10 +213,12 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.env}, {n} env instances per GPU ({total_envs} total), random policy "
                                    f"U(-1,1)^2, auto-reset on, 250 substeps of 2e-5 s per env step",
-                       "envs_per_gpu": n, "substeps": 250, "parallelism": f"env-sharded x{world}, no collective"},
+                       "envs_per_gpu": n, "substeps": 250, "parallelism": f"env-sharded x{world}, no collective",
+                       "preroll_steps": preroll, "preroll_window_ms_per_step": [round(x, 4) for x in win_ms]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": sim.step_kernel_name(), "kernel_ms": kern_ms,
+                         "kernel_ms_min_median_max": [float(kms.min()), float(np.median(kms)), float(kms.max())],
                          "algorithmic_bytes_per_env_step": sim.step_bytes_per_env(),
                          "note": "state stays in registers for 250 fused substeps, so HBM traffic is ~0.1% of peak by "
                                  "construction; the binding resource is fp32 VALU issue (see DESIGN.md)"},
@@ -143,21 +226,22 @@ def main():
             "last_step_terminated": n_done,
         }
         # HBM bytes per launch from the PMC counters cannot be collected from inside this process; when the committed
-        # rocprofv3 summary of this exact workload exists, report its per-launch figure (FETCH_SIZE x2 gfx950 correction
-        # + WRITE_SIZE, separate --pmc passes), else null
+        # rocprofv3 summary of this exact workload exists, report its per-launch figure (separate --pmc passes,
+        # FETCH_SIZE / WRITE_SIZE as MI355X_MICROARCH.md prescribes), else null
         try:
             if args.env == "Env03-v2" and n == 65536:
-                summ = json.load(open(os.path.join(ROOT, "profiles", "r01_env03_summary.json")))
-                prof = summ["hbm_traffic"]
-                out["roofline"]["traffic"] = prof["fetch_bytes_x2_corrected"] + prof["write_bytes"]
-                # the resource that does bind (same PMC summary): share of wave cycles with the VALU busy, one wave per SIMD
-                out["roofline"]["valu"] = {"busy_frac": summ["valu_busy_frac"], "wait_frac": summ["wait_frac"],
-                                           "valu_insts_per_wave_per_step": summ["per_wave_step"]["SQ_INSTS_VALU"]}
-                out["roofline"]["traffic_source"] = "profiles/r01_env03_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+                summ = json.load(open(os.path.join(ROOT, "profiles", "r02_env03_summary.json")))
+                out["roofline"]["traffic"] = summ["hbm_traffic"]["bytes_per_launch"]
+                out["roofline"]["valu"] = summ.get("valu")
+                out["roofline"]["traffic_source"] = "profiles/r02_env03_summary.json (rocprofv3 --pmc, same command line)"
         except Exception:
             pass
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.env)
+            try:
+                out["cpu_baseline_closed_form"] = cpu_baseline_closed_form(args.env)
+            except Exception as e:  # the host build is test infrastructure; its absence must not break the bench line
+                out["cpu_baseline_closed_form"] = {"error": str(e)}
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

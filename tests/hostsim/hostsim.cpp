@@ -2,6 +2,8 @@
 // TEST INFRASTRUCTURE ONLY: lets the CPU test-suite check the fp32 algorithm the HIP kernel runs (and a
 // double instantiation of the same closed forms) against oracle/ without a GPU.  Never loaded by the
 // product; the product path is libbrs_hip.so and fails loudly without a GPU.
+#include <omp.h>
+
 #include <cstring>
 #include <memory>
 #include <vector>
@@ -62,8 +64,9 @@ template <typename R, bool BLK> struct HostSim : IHost {
   }
   void close_stream(Stream<R>& rng, ES& S, size_t i) { S.rng_ctr = rng.ctr; spos[i] = rng.script_pos; }
   void physics(const double* ctrl, int nsub) override {
-    R buf[LDS_WORDS_ENV03];
+#pragma omp parallel for schedule(dynamic, 4)
     for (size_t i = 0; i < N; i++) {
+      R buf[LDS_WORDS_ENV03];
       Store<R> st{buf, 1};
       physics_mem<R, BLK, R>(P, st, d.data(), f.data(), ii.data(), N, i, (R)ctrl[2 * i], (R)ctrl[2 * i + 1], nsub);
     }
@@ -81,8 +84,9 @@ template <typename R, bool BLK> struct HostSim : IHost {
     }
   }
   void step(const float* act, float* obs, float* rew, uint8_t* term, uint8_t* trunc, float* tobs) override {
-    R buf[LDS_WORDS_ENV03];
+#pragma omp parallel for schedule(dynamic, 4)
     for (size_t i = 0; i < N; i++) {
+      R buf[LDS_WORDS_ENV03];
       Stream<R> rng;
       rng.open(P.seed, P.gid_base + (int64_t)i, 0u);
       if (!scripts[i].empty()) { rng.script = scripts[i].data(); rng.script_n = (int)scripts[i].size(); rng.script_pos = spos[i]; }
@@ -148,6 +152,7 @@ void* hs_create(int variant, int n, int use_double, uint64_t seed, int64_t gid_b
   return new HostSim<float, false>(variant, n, seed, gid_base, auto_reset, noise, max_steps, nsub, h);
 }
 void hs_destroy(void* h) { delete (IHost*)h; }
+void hs_set_threads(int n) { omp_set_num_threads(n > 0 ? n : 1); }
 int hs_nq(void* h) { return ((IHost*)h)->nq(); }
 int hs_nv(void* h) { return ((IHost*)h)->nv(); }
 void hs_set_state(void* h, const double* a, const double* b, const double* c, const double* d) { ((IHost*)h)->set_state(a, b, c, d); }

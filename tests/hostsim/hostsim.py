@@ -18,6 +18,7 @@ def lib():
         L = C.CDLL(_LIB)
         vp, dp, fp, u8p = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_uint8)
         L.hs_create.restype = vp
+        L.hs_set_threads.argtypes = [C.c_int]
         L.hs_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double]
         for name, args in dict(hs_destroy=[vp], hs_nq=[vp], hs_nv=[vp], hs_set_state=[vp, dp, dp, dp, dp],
                                hs_get_state=[vp, dp, dp, dp, dp], hs_get_aux=[vp, dp], hs_set_aux=[vp, dp],
@@ -37,10 +38,11 @@ class HostSim:
     """same surface as oracle.Oracle, running the kernel's own source on the CPU in float or double"""
 
     def __init__(self, variant, num_envs, seed=0, env_index_base=0, auto_reset=False, noise=None, max_episode_steps=0,
-                 substeps=0, timestep=0.0, double=False):
+                 substeps=0, timestep=0.0, double=False, threads=1):
         if isinstance(variant, str):
             variant = VARIANTS[variant]
         self.L = lib()
+        self.L.hs_set_threads(int(threads))  # process-wide OpenMP setting (the per-env loops are data-parallel)
         nz = -1 if noise is None else int(bool(noise))
         self.h = self.L.hs_create(variant, num_envs, int(double), seed, env_index_base, int(auto_reset), nz,
                                   max_episode_steps, substeps, timestep)
