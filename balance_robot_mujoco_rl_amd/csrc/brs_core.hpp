@@ -69,7 +69,8 @@ __device__ __forceinline__ unsigned long long* brs_tim_slots() {  // 16 x u64 pe
 namespace brs {
 
 #if defined(BRS_STATS) && !defined(__HIP_DEVICE_COMPILE__)
-struct Stats { long substeps, solves[3], iters[3], passA[3], backtracks[3]; int last_iters[3]; long hist[17], trips; };
+struct Stats { long substeps, solves[3], iters[3], passA[3], backtracks[3]; int last_iters[3]; long hist[17], trips;
+               long cp_calls, cp_reach, cp_torso, cp_wheel, cp_nc, cp_tight_torso, cp_tight_wheel, nfr_hist[9], nfb_hist[5], nc_hist[5]; };
 inline Stats& stats() { static thread_local Stats s{}; return s; }
 #define BRS_STAT(expr) do { expr; } while (0)
 #else
@@ -559,14 +560,21 @@ template <typename R, bool BLK> struct Sim {
   }
 
   // ---- coupled (block <-> robot) contacts: this project's OWN analytic generator (MuJoCo: mjc_BoxBox / libccd)
-  static BRS_HD R point_box(const R* p, R sx, R sy, R sz, int* axis, R* sign) {
-    R d0 = abs_(p[0]) - sx, d1 = abs_(p[1]) - sy, d2 = abs_(p[2]) - sz;
-    R best = d0; int ax = 0;
-    if (d1 > best) { best = d1; ax = 1; }
-    if (d2 > best) { best = d2; ax = 2; }
-    R pv = pick3<R>(ax, p);
-    *axis = ax; *sign = pv >= 0 ? (R)1 : (R)-1;
-    return best;
+  // signed distance of a point (box frame) to a box: Euclidean outside, max-axis inside; outward normal
+  static BRS_HD R point_box(const R* p, R sx, R sy, R sz, R* nrm) {
+    const R q0 = abs_(p[0]) - sx, q1 = abs_(p[1]) - sy, q2 = abs_(p[2]) - sz;
+    const R s0 = p[0] >= 0 ? (R)1 : (R)-1, s1 = p[1] >= 0 ? (R)1 : (R)-1, s2 = p[2] >= 0 ? (R)1 : (R)-1;
+    const bool outside = (q0 > 0) | (q1 > 0) | (q2 > 0);
+    const R m0 = max_(q0, (R)0), m1 = max_(q1, (R)0), m2 = max_(q2, (R)0);
+    const R dd = sqrt_(m0 * m0 + m1 * m1 + m2 * m2), idd = rcp_(max_(dd, (R)1e-30));
+    int ax = 0;
+    R best = q0;
+    if (q1 > best) { best = q1; ax = 1; }
+    if (q2 > best) { best = q2; ax = 2; }
+    nrm[0] = outside ? s0 * m0 * idd : (ax == 0 ? s0 : (R)0);
+    nrm[1] = outside ? s1 * m1 * idd : (ax == 1 ? s1 : (R)0);
+    nrm[2] = outside ? s2 * m2 * idd : (ax == 2 ? s2 : (R)0);
+    return outside ? dd : best;
   }
   // MuJoCo's mju_makeFrame on a unit normal fw[0..2]: fills tangents fw[3..8]
   static BRS_HD void make_frame(R* fw) {
@@ -624,7 +632,9 @@ template <typename R, bool BLK> struct Sim {
     mulT_(F.RT, dW, cB);  // block centre in the torso frame
     R d2 = dot_(cB, cB);
     R reach = P.torso_brad + P.torso_cz + P.block_brad + c.margin;  // generous: torso geom centre is cz up
+    BRS_STAT(stats().cp_calls++);
     if (d2 > reach * reach) return;
+    BRS_STAT(stats().cp_reach++);
     R RTB[9];  // block->torso
 #pragma unroll
     for (int i = 0; i < 3; i++)
@@ -632,124 +642,230 @@ template <typename R, bool BLK> struct Sim {
       for (int j = 0; j < 3; j++) RTB[3 * i + j] = F.RT[i] * F.RB[j] + F.RT[3 + i] * F.RB[3 + j] + F.RT[6 + i] * F.RB[6 + j];
     R s = P.block_s;
     BRS_TIC(10);
-    // (i) torso box <-> block box (OWN generator, mirrored in oracle/brs_oracle.c box_box_own): SAT over the 6 face
-    // axes, reference face = minimum overlap, contacts = incident-face vertices behind it and inside its rectangle,
-    // else the deepest incident vertex clamped into the rectangle.  <= 4 points.  No runtime-indexed arrays.
+    // (i) torso box <-> block box: the standard clipped-polygon box-box (15-axis SAT; face case: the incident face clipped
+    // against the reference rectangle, <= 8 points, the 4 deepest kept; edge case: one point between the closest points of
+    // the two edges).  Same specification as oracle/brs_oracle.c bo_box_box_points (axis choice, candidate order,
+    // reduction); MuJoCo's mjc_BoxBox point sets are UNPINNED.  No runtime-indexed register arrays: the <= 16 clip
+    // candidates are parked in the lane's LDS column (robot<->floor slot region, not yet written in this substep) and
+    // only the kept ones are read back by the insertion loop.
     R cg[3] = {cB[0], cB[1], cB[2] - P.torso_cz};  // block centre relative to the torso geom centre
     R dd2 = dot_(cg, cg), rr0 = P.torso_brad + P.block_brad + c.margin;
     if (dd2 <= rr0 * rr0) {
       const R sT[3] = {P.torso_sx, P.torso_sy, P.torso_sz};
-      R best = (R)1e30;
-      int bestax = 0;
+      R Q[9];
+#pragma unroll
+      for (int i = 0; i < 9; i++) Q[i] = abs_(RTB[i]);
+      R bestF = (R)-1e30, bestE = (R)-1e30;
+      int axF = 0, axE = -1;
       bool sep = false;
 #pragma unroll
       for (int k = 0; k < 3; k++) {
-        R ext = s * (abs_(RTB[3 * k]) + abs_(RTB[3 * k + 1]) + abs_(RTB[3 * k + 2]));
-        R ov = sT[k] + ext - abs_(cg[k]);
-        if (ov < -c.margin) sep = true;
-        if (ov < best) { best = ov; bestax = k; }
+        R sp = abs_(cg[k]) - sT[k] - s * (Q[3 * k] + Q[3 * k + 1] + Q[3 * k + 2]);
+        sep = sep | (sp > c.margin);
+        const bool better = sp > bestF;
+        bestF = better ? sp : bestF; axF = better ? k : axF;
       }
 #pragma unroll
       for (int j = 0; j < 3; j++) {
         R dB = cg[0] * RTB[j] + cg[1] * RTB[3 + j] + cg[2] * RTB[6 + j];
-        R ext = sT[0] * abs_(RTB[j]) + sT[1] * abs_(RTB[3 + j]) + sT[2] * abs_(RTB[6 + j]);
-        R ov = s + ext - abs_(dB);
-        if (ov < -c.margin) sep = true;
-        if (ov < best) { best = ov; bestax = 3 + j; }
+        R sp = abs_(dB) - s - (sT[0] * Q[j] + sT[1] * Q[3 + j] + sT[2] * Q[6 + j]);
+        sep = sep | (sp > c.margin);
+        const bool better = sp > bestF;
+        bestF = better ? sp : bestF; axF = better ? 3 + j : axF;
+      }
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+          R len2 = (R)1 - RTB[3 * i + j] * RTB[3 * i + j];
+          R cl = cg[i2] * RTB[3 * i1 + j] - cg[i1] * RTB[3 * i2 + j];
+          R rT = sT[i1] * Q[3 * i2 + j] + sT[i2] * Q[3 * i1 + j], rB = s * (Q[3 * i + j1] + Q[3 * i + j2]);
+          R sp = (abs_(cl) - rT - rB) * rsqrt_(max_(len2, (R)1e-12));
+          const bool ok = len2 >= (R)1e-6;
+          sep = sep | (ok & (sp > c.margin));
+          const bool better = ok & (sp > bestE);
+          bestE = better ? sp : bestE; axE = better ? 3 * i + j : axE;
+        }
       }
       if (!sep) {
-        // candidates of the incident face first (cheap, case-specific), insertion afterwards in ONE uniform loop
-        R cpos[4][3], cdist[4], nrm[3];
-        bool cval[4];
-        R fb_dist = (R)1e30, fbp[3] = {0, 0, 0};
-        if (bestax < 3) {
-          const int k = bestax;
-          R sg = pick3(k, cg) >= 0 ? (R)1 : (R)-1;
-          R rk[3] = {pick3(k, RTB[0], RTB[3], RTB[6]), pick3(k, RTB[1], RTB[4], RTB[7]), pick3(k, RTB[2], RTB[5], RTB[8])};
-          int js = 0;
-          if (abs_(rk[1]) > abs_(rk[0])) js = 1;
-          if (abs_(rk[2]) > abs_(pick3(js, rk))) js = 2;
-          R sj = -sg * (pick3(js, rk) >= 0 ? (R)1 : (R)-1);
-          int a1 = js == 2 ? 0 : js + 1;
+        const bool use_edge = (axE >= 0) & (bestE > bestF + (R)0.05 * abs_(bestF) + (R)1e-5);
+        if (use_edge) {
+          if (bestE < c.margin) {
+            const int i = axE / 3, j = axE - 3 * i;
+            const int i1 = i == 2 ? 0 : i + 1, i2 = i == 0 ? 2 : i - 1;
+            R bj[3] = {pick3(j, RTB[0], RTB[1], RTB[2]), pick3(j, RTB[3], RTB[4], RTB[5]), pick3(j, RTB[6], RTB[7], RTB[8])};
+            const R bji = pick3(i, bj), bji1 = pick3(i1, bj), bji2 = pick3(i2, bj);
+            R il = rsqrt_((R)1 - bji * bji);
+            // L = e_i x b_j : L[i1] = -b_j[i2], L[i2] = b_j[i1]
+            R Lv1 = -bji2 * il, Lv2 = bji1 * il;
+            R L[3];
 #pragma unroll
-          for (int i = 0; i < 3; i++) nrm[i] = i == k ? sg : (R)0;
-          R sTk = pick3(k, sT);
+            for (int m = 0; m < 3; m++) L[m] = m == i1 ? Lv1 : (m == i2 ? Lv2 : (R)0);
+            R sgn = dot_(L, cg) < 0 ? (R)-1 : (R)1;
 #pragma unroll
-          for (int v = 0; v < 4; v++) {
-            R loc[3], p[3];
+            for (int m = 0; m < 3; m++) L[m] *= sgn;
+            R pA[3], pB[3] = {cg[0], cg[1], cg[2]};
 #pragma unroll
-            for (int i = 0; i < 3; i++) loc[i] = i == js ? sj * s : (((i == a1) ? (v & 1) : (v & 2)) ? s : -s);
-            mul_(RTB, loc, p);
-            p[0] += cg[0]; p[1] += cg[1]; p[2] += cg[2];
-            R dist = sg * pick3(k, p) - sTk;
-            bool lat = true;  // (bitwise on purpose: && / || chains become exec-mask branches)
+            for (int m = 0; m < 3; m++) pA[m] = m == i ? (R)0 : (L[m] >= 0 ? sT[m] : -sT[m]);
 #pragma unroll
-            for (int i = 0; i < 3; i++) lat = lat & ((i == k) | (abs_(p[i]) <= sT[i] + c.margin));
-            cval[v] = (dist < c.margin) & lat;
-            cdist[v] = dist;
+            for (int m = 0; m < 3; m++) {
+              R bm[3] = {RTB[m], RTB[3 + m], RTB[6 + m]};
+              R sg = m == j ? (R)0 : (dot_(L, bm) >= 0 ? -s : s);
 #pragma unroll
-            for (int i = 0; i < 3; i++) cpos[v][i] = p[i] - nrm[i] * dist * (R)0.5;
-            const bool deeper = dist < fb_dist;  // deepest incident vertex (its clamped position is only needed in the
-            fb_dist = deeper ? dist : fb_dist;   // rare no-vertex-inside case below)
+              for (int q = 0; q < 3; q++) pB[q] += sg * bm[q];
+            }
+            R w[3] = {pA[0] - pB[0], pA[1] - pB[1], pA[2] - pB[2]};
+            R dA = pick3(i, w), dBv = dot_(w, bj), iden = rcp_((R)1 - bji * bji);
+            R al = (bji * dBv - dA) * iden, be = (dBv - bji * dA) * iden;
+            const R sTi = pick3(i, sT);
+            al = max_(-sTi, min_(sTi, al)); be = max_(-s, min_(s, be));
+            R pos[3];
 #pragma unroll
-            for (int i = 0; i < 3; i++) fbp[i] = deeper ? p[i] : fbp[i];
+            for (int m = 0; m < 3; m++) pos[m] = (R)0.5 * (pA[m] + (m == i ? al : (R)0) + pB[m] + be * bj[m]);
+            pos[2] += P.torso_cz;
+            R fw[9];
+            world_frame(F, L, fw);
+            add_coupled(P, st, F, S, pos, fw, bestE, 0, false);
           }
         } else {
-          const int j = bestax - 3;
-          R bj[3] = {pick3(j, RTB[0], RTB[1], RTB[2]), pick3(j, RTB[3], RTB[4], RTB[5]), pick3(j, RTB[6], RTB[7], RTB[8])};
-          R dB = dot_(cg, bj), sgB = dB >= 0 ? (R)1 : (R)-1;
+          // face case.  Reference frame coordinates (u, v, g): u, v span the reference rectangle |u| <= ra, |v| <= rb, g is
+          // the signed distance to the reference face.  Incident face = centre Cc +- H1 +- H2 in those coordinates; a
+          // candidate (u, v, g) maps back to the torso geom frame as  pos = u A1 + v A2 + (half + g/2) A3 + A0.
+          R Cc[3], H1[3], H2[3], A0[3], A1[3], A2[3], A3[3], nrm[3], ra, rb, half;
+          if (axF < 3) {
+            const int k = axF, j1 = k == 2 ? 0 : k + 1, j2 = k == 0 ? 2 : k - 1;
+            const R sg = pick3(k, cg) >= 0 ? (R)1 : (R)-1;
+            R rk[3] = {pick3(k, RTB[0], RTB[3], RTB[6]), pick3(k, RTB[1], RTB[4], RTB[7]), pick3(k, RTB[2], RTB[5], RTB[8])};  // row k
+            int js = 0;
+            if (abs_(rk[1]) > abs_(rk[0])) js = 1;
+            if (abs_(rk[2]) > abs_(pick3(js, rk))) js = 2;
+            const R sj = -sg * (pick3(js, rk) >= 0 ? (R)1 : (R)-1);
+            const int a1 = js == 2 ? 0 : js + 1, a2 = js == 0 ? 2 : js - 1;
+            // block axes (torso frame) js, a1, a2 = columns of RTB
+            R bs[3] = {pick3(js, RTB[0], RTB[1], RTB[2]), pick3(js, RTB[3], RTB[4], RTB[5]), pick3(js, RTB[6], RTB[7], RTB[8])};
+            R b1[3] = {pick3(a1, RTB[0], RTB[1], RTB[2]), pick3(a1, RTB[3], RTB[4], RTB[5]), pick3(a1, RTB[6], RTB[7], RTB[8])};
+            R b2[3] = {pick3(a2, RTB[0], RTB[1], RTB[2]), pick3(a2, RTB[3], RTB[4], RTB[5]), pick3(a2, RTB[6], RTB[7], RTB[8])};
+            R pc[3] = {cg[0] + sj * s * bs[0], cg[1] + sj * s * bs[1], cg[2] + sj * s * bs[2]};
+            const R sTk = pick3(k, sT);
+            Cc[0] = pick3(j1, pc); Cc[1] = pick3(j2, pc); Cc[2] = sg * pick3(k, pc) - sTk;
+            H1[0] = s * pick3(j1, b1); H1[1] = s * pick3(j2, b1); H1[2] = sg * s * pick3(k, b1);
+            H2[0] = s * pick3(j1, b2); H2[1] = s * pick3(j2, b2); H2[2] = sg * s * pick3(k, b2);
+            ra = pick3(j1, sT); rb = pick3(j2, sT); half = sTk;
 #pragma unroll
-          for (int i = 0; i < 3; i++) nrm[i] = sgB * bj[i];
-          int ks = 0;
-          if (abs_(bj[1]) > abs_(bj[0])) ks = 1;
-          if (abs_(bj[2]) > abs_(pick3(ks, bj))) ks = 2;
-          R sk = sgB * (pick3(ks, bj) >= 0 ? (R)1 : (R)-1);
-          int a1 = ks == 2 ? 0 : ks + 1;
+            for (int m = 0; m < 3; m++) {
+              A0[m] = 0; A1[m] = m == j1 ? (R)1 : (R)0; A2[m] = m == j2 ? (R)1 : (R)0; A3[m] = m == k ? sg : (R)0;
+              nrm[m] = m == k ? sg : (R)0;
+            }
+          } else {
+            const int j = axF - 3, i1 = j == 2 ? 0 : j + 1, i2 = j == 0 ? 2 : j - 1;
+            R bj[3] = {pick3(j, RTB[0], RTB[1], RTB[2]), pick3(j, RTB[3], RTB[4], RTB[5]), pick3(j, RTB[6], RTB[7], RTB[8])};
+            R bi1[3] = {pick3(i1, RTB[0], RTB[1], RTB[2]), pick3(i1, RTB[3], RTB[4], RTB[5]), pick3(i1, RTB[6], RTB[7], RTB[8])};
+            R bi2[3] = {pick3(i2, RTB[0], RTB[1], RTB[2]), pick3(i2, RTB[3], RTB[4], RTB[5]), pick3(i2, RTB[6], RTB[7], RTB[8])};
+            const R sgB = dot_(cg, bj) >= 0 ? (R)1 : (R)-1;
+            int ks = 0;
+            if (abs_(bj[1]) > abs_(bj[0])) ks = 1;
+            if (abs_(bj[2]) > abs_(pick3(ks, bj))) ks = 2;
+            const R sk = sgB * (pick3(ks, bj) >= 0 ? (R)1 : (R)-1);
+            const int a1 = ks == 2 ? 0 : ks + 1, a2 = ks == 0 ? 2 : ks - 1;
+            const R sTs = pick3(ks, sT), sT1 = pick3(a1, sT), sT2 = pick3(a2, sT);
+            // incident torso face: centre sk sT[ks] e_ks, half edges sT[a1] e_a1, sT[a2] e_a2; into the block frame: R^T (x - cg)
+            R rel[3];
+#pragma unroll
+            for (int m = 0; m < 3; m++) rel[m] = (m == ks ? sk * sTs : (R)0) - cg[m];
+            Cc[0] = dot_(bi1, rel); Cc[1] = dot_(bi2, rel); Cc[2] = -sgB * dot_(bj, rel) - s;
+            H1[0] = sT1 * pick3(a1, bi1); H1[1] = sT1 * pick3(a1, bi2); H1[2] = -sgB * sT1 * pick3(a1, bj);
+            H2[0] = sT2 * pick3(a2, bi1); H2[1] = sT2 * pick3(a2, bi2); H2[2] = -sgB * sT2 * pick3(a2, bj);
+            ra = s; rb = s; half = s;
+#pragma unroll
+            for (int m = 0; m < 3; m++) { A0[m] = cg[m]; A1[m] = bi1[m]; A2[m] = bi2[m]; A3[m] = -sgB * bj[m]; nrm[m] = sgB * bj[m]; }
+          }
+          // incident quad, in order around the face
+          R V[4][3];
+#pragma unroll
+          for (int q = 0; q < 3; q++) {
+            V[0][q] = Cc[q] - H1[q] - H2[q]; V[1][q] = Cc[q] + H1[q] - H2[q];
+            V[2][q] = Cc[q] + H1[q] + H2[q]; V[3][q] = Cc[q] - H1[q] + H2[q];
+          }
+          R* scr = st.base + (SLOT_ROBOT * SLOT_WORDS) * st.stride;  // 48 words of scratch: candidate c at words 3c .. 3c+2
+          uint32_t vmask = 0;
+          bool ins[4];
 #pragma unroll
           for (int v = 0; v < 4; v++) {
-            R loc[3], rel[3], pB[3];
+            ins[v] = (abs_(V[v][0]) <= ra) & (abs_(V[v][1]) <= rb);
+            vmask |= (ins[v] & (V[v][2] < c.margin)) ? (1u << v) : 0u;
 #pragma unroll
-            for (int i = 0; i < 3; i++) loc[i] = i == ks ? sk * sT[i] : (((i == a1) ? (v & 1) : (v & 2)) ? sT[i] : -sT[i]);
-#pragma unroll
-            for (int i = 0; i < 3; i++) rel[i] = loc[i] - cg[i];
-            mulT_(RTB, rel, pB);
-            R dist = -sgB * pick3(j, pB) - s;
-            bool lat = true;
-#pragma unroll
-            for (int i = 0; i < 3; i++) lat = lat & ((i == j) | (abs_(pB[i]) <= s + c.margin));
-            cval[v] = (dist < c.margin) & lat;
-            cdist[v] = dist;
-#pragma unroll
-            for (int i = 0; i < 3; i++) cpos[v][i] = loc[i] + nrm[i] * dist * (R)0.5;
-            const bool deeper = dist < fb_dist;
-            fb_dist = deeper ? dist : fb_dist;
-#pragma unroll
-            for (int i = 0; i < 3; i++) fbp[i] = deeper ? pB[i] : fbp[i];
+            for (int q = 0; q < 3; q++) scr[(3 * v + q) * st.stride] = V[v][q];
           }
-        }
-        if (!(cval[0] | cval[1] | cval[2] | cval[3]) & (fb_dist < c.margin)) {  // no vertex inside the rectangle: clamped deepest one
-          cval[0] = true; cdist[0] = fb_dist;
-          if (bestax < 3) {  // fbp in the torso geom frame: clamp into the reference rectangle
 #pragma unroll
-            for (int i = 0; i < 3; i++) cpos[0][i] = (i == bestax ? fbp[i] : max_(-sT[i], min_(sT[i], fbp[i]))) - nrm[i] * fb_dist * (R)0.5;
-          } else {           // fbp in the block frame: clamp there, map back
-            R q[3], back[3];
+          for (int e = 0; e < 4; e++) {
+            const int e1 = (e + 1) & 3;
+            const R du = V[e1][0] - V[e][0], dv = V[e1][1] - V[e][1], dg = V[e1][2] - V[e][2];
+            // Liang-Barsky against |u| <= ra, |v| <= rb
+            R t0 = 0, t1 = 1;
+            bool ok = true;
+            const R pp[4] = {-du, du, -dv, dv}, qq[4] = {V[e][0] + ra, ra - V[e][0], V[e][1] + rb, rb - V[e][1]};
 #pragma unroll
-            for (int i = 0; i < 3; i++) q[i] = i == bestax - 3 ? fbp[i] : max_(-s, min_(s, fbp[i]));
-            mul_(RTB, q, back);
-#pragma unroll
-            for (int i = 0; i < 3; i++) cpos[0][i] = back[i] + cg[i] + nrm[i] * fb_dist * (R)0.5;
+            for (int b4 = 0; b4 < 4; b4++) {
+              const bool zero = pp[b4] == (R)0;
+              const R r = qq[b4] * rcp_(zero ? (R)1 : pp[b4]);
+              ok = ok & !(zero & (qq[b4] < 0));
+              t0 = (!zero & (pp[b4] < 0) & (r > t0)) ? r : t0;
+              t1 = (!zero & (pp[b4] > 0) & (r < t1)) ? r : t1;
+            }
+            ok = ok & (t0 < t1);
+            const R g0 = V[e][2] + t0 * dg, g1 = V[e][2] + t1 * dg;
+            vmask |= (ok & !ins[e] & (g0 < c.margin)) ? (1u << (4 + 2 * e)) : 0u;
+            vmask |= (ok & !ins[e1] & (g1 < c.margin)) ? (1u << (5 + 2 * e)) : 0u;
+            scr[(3 * (4 + 2 * e) + 0) * st.stride] = V[e][0] + t0 * du; scr[(3 * (4 + 2 * e) + 1) * st.stride] = V[e][1] + t0 * dv;
+            scr[(3 * (4 + 2 * e) + 2) * st.stride] = g0;
+            scr[(3 * (5 + 2 * e) + 0) * st.stride] = V[e][0] + t1 * du; scr[(3 * (5 + 2 * e) + 1) * st.stride] = V[e][1] + t1 * dv;
+            scr[(3 * (5 + 2 * e) + 2) * st.stride] = g1;
           }
-        }
-        if (cval[0] | cval[1] | cval[2] | cval[3]) {
-          R fw[9];
-          world_frame(F, nrm, fw);  // one contact frame for the whole patch
-          bool first_in_patch = true;
+          {  // rectangle corners inside the incident parallelogram: corner = V0 + al (V1 - V0) + be (V3 - V0)
+            const R e1u = 2 * H1[0], e1v = 2 * H1[1], e2u = 2 * H2[0], e2v = 2 * H2[1];
+            const R det = e1u * e2v - e1v * e2u;
+            const bool dok = abs_(det) > (R)1e-30;
+            const R idet = rcp_(dok ? det : (R)1);
 #pragma unroll
-          for (int v = 0; v < 4; v++) {
-            if (cval[v]) {
-              R pos[3] = {cpos[v][0], cpos[v][1], cpos[v][2] + P.torso_cz};
-              add_coupled(P, st, F, S, pos, fw, cdist[v], 0, !first_in_patch);
+            for (int q = 0; q < 4; q++) {
+              const R cu = (q & 1) ? ra : -ra, cv = (q & 2) ? rb : -rb, ru = cu - V[0][0], rv = cv - V[0][1];
+              const R al = (ru * e2v - rv * e2u) * idet, be = (e1u * rv - e1v * ru) * idet;
+              const R g = V[0][2] + al * (2 * H1[2]) + be * (2 * H2[2]);
+              const bool in = dok & (al > 0) & (al < 1) & (be > 0) & (be < 1);
+              vmask |= (in & (g < c.margin)) ? (1u << (12 + q)) : 0u;
+              scr[(3 * (12 + q) + 0) * st.stride] = cu; scr[(3 * (12 + q) + 1) * st.stride] = cv; scr[(3 * (12 + q) + 2) * st.stride] = g;
+            }
+          }
+          int cnt = 0;
+#pragma unroll
+          for (int q = 0; q < 16; q++) cnt += (int)((vmask >> q) & 1u);
+          if (cnt > 4) {  // rare: keep the 4 deepest (ties: lower candidate index)
+            uint32_t keep = 0;
+            for (int pass = 0; pass < 4; pass++) {
+              R bd = (R)1e30;
+              int bi = 0;
+              for (int q = 0; q < 16; q++) {
+                const R g = scr[(3 * q + 2) * st.stride];
+                const bool take = (((vmask & ~keep) >> q) & 1u) && g < bd;
+                bd = take ? g : bd; bi = take ? q : bi;
+              }
+              keep |= 1u << bi;
+            }
+            vmask = keep;
+          }
+          if (vmask) {
+            R fw[9];
+            world_frame(F, nrm, fw);  // one contact frame for the whole patch
+            bool first_in_patch = true;
+            while (vmask) {
+              const int q = __builtin_ctz(vmask);
+              vmask &= vmask - 1u;
+              const R u = scr[(3 * q) * st.stride], v = scr[(3 * q + 1) * st.stride], g = scr[(3 * q + 2) * st.stride];
+              const R wv = half + (R)0.5 * g;
+              R pos[3] = {A0[0] + u * A1[0] + v * A2[0] + wv * A3[0], A0[1] + u * A1[1] + v * A2[1] + wv * A3[1],
+                          A0[2] + u * A1[2] + v * A2[2] + wv * A3[2] + P.torso_cz};
+              add_coupled(P, st, F, S, pos, fw, g, 0, !first_in_patch);
               first_in_patch = false;
             }
           }
@@ -758,7 +874,9 @@ template <typename R, bool BLK> struct Sim {
     }
     BRS_TOC(10);
     BRS_TIC(11);
-    // (ii) wheel cylinder <-> block box: single deepest candidate per wheel
+    // (ii) wheel cylinder <-> block box: ONE point per wheel, the deepest of the closest-feature candidates (a) block
+    // vertices vs cylinder, (b) block edges vs barrel, (c) two cylinder surface points vs box -- same order and rules as
+    // oracle/brs_oracle.c bo_box_cyl_point (MuJoCo: general convex collider, one point; UNPINNED)
 #pragma unroll
     for (int wsel = 1; wsel <= 2; wsel++) {
       R wp[3] = {wsel == 1 ? -P.wheel_px : P.wheel_px, (R)0, P.wheel_pz};
@@ -775,15 +893,45 @@ template <typename R, bool BLK> struct Sim {
         // branch-free on purpose: 8 vertices x 2 wheels of two-sided branches cost more than the selects
         R xi = p[0], rho = sqrt_(p[1] * p[1] + p[2] * p[2]);
         R drad = rho - P.wheel_r, dax = abs_(xi) - P.wheel_hl;
+        const bool rim = (drad > 0) & (dax > 0);
         const bool radial = drad >= dax;
         const R ir = rcp_(max_(rho, (R)1e-9));
-        const R dist = radial ? drad : dax;
-        const R nrm[3] = {radial ? (R)0 : (xi >= 0 ? (R)1 : (R)-1), radial ? p[1] * ir : (R)0, radial ? p[2] * ir : (R)0};
-        const bool take = (!radial | (rho >= (R)1e-9)) & (dist < best);
+        const R drim = sqrt_(drad * drad + dax * dax), idr = rcp_(max_(drim, (R)1e-20));
+        const R dist = rim ? drim : (radial ? drad : dax);
+        const R sx = xi >= 0 ? (R)1 : (R)-1;
+        const R kx = rim ? dax * idr : (radial ? (R)0 : (R)1), kr = rim ? drad * idr : (radial ? (R)1 : (R)0);
+        const R nrm[3] = {sx * kx, kr * p[1] * ir, kr * p[2] * ir};
+        const bool take = (rim | !radial | (rho >= (R)1e-9)) & (dist < best);
         best = take ? dist : best;
         found = found | take;
 #pragma unroll
         for (int j = 0; j < 3; j++) { bn[j] = take ? nrm[j] : bn[j]; bpos[j] = take ? p[j] + wp[j] - nrm[j] * dist * (R)0.5 : bpos[j]; }
+      }
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        const int j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+        const R dir[3] = {RTB[j], RTB[3 + j], RTB[6 + j]};
+        const R dd = dir[1] * dir[1] + dir[2] * dir[2];
+        const bool dok = dd >= (R)1e-8;
+        const R idd = rcp_(dok ? dd : (R)1);
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          R loc[3];
+          loc[j] = 0; loc[j1] = (e & 1) ? s : -s; loc[j2] = (e & 2) ? s : -s;
+          R o[3];
+          mul_(RTB, loc, o);
+          o[0] += d[0]; o[1] += d[1]; o[2] += d[2];
+          const R tau = -(o[1] * dir[1] + o[2] * dir[2]) * idd;
+          const R p[3] = {o[0] + tau * dir[0], o[1] + tau * dir[1], o[2] + tau * dir[2]};
+          const R rho = sqrt_(p[1] * p[1] + p[2] * p[2]), ir = rcp_(max_(rho, (R)1e-9));
+          const R dist = rho - P.wheel_r;
+          const bool take = dok & (abs_(tau) < s) & !(abs_(p[0]) > P.wheel_hl) & !(rho < (R)1e-9) & (dist < best);
+          best = take ? dist : best;
+          found = found | take;
+          const R nrm[3] = {(R)0, p[1] * ir, p[2] * ir};
+#pragma unroll
+          for (int q = 0; q < 3; q++) { bn[q] = take ? nrm[q] : bn[q]; bpos[q] = take ? p[q] + wp[q] - nrm[q] * dist * (R)0.5 : bpos[q]; }
+        }
       }
       R xid = d[0], rho = sqrt_(d[1] * d[1] + d[2] * d[2]);
       if (rho > (R)1e-9) {
@@ -793,18 +941,18 @@ template <typename R, bool BLK> struct Sim {
           R xc = min_(max_(xid, -P.wheel_hl), P.wheel_hl), rq = P.wheel_r;
           if (cand == 1) { xc = xid >= 0 ? P.wheel_hl : -P.wheel_hl; rq = min_(rho, P.wheel_r); }
           R q[3] = {xc, rq * d[1] * ir, rq * d[2] * ir};  // relative to the wheel centre
-          R rel[3] = {q[0] - d[0], q[1] - d[1], q[2] - d[2]}, p[3];
+          R rel[3] = {q[0] - d[0], q[1] - d[1], q[2] - d[2]}, p[3], nb[3];
           mulT_(RTB, rel, p);
-          int ax; R sg;
-          R dist = point_box(p, s, s, s, &ax, &sg);
+          R dist = point_box(p, s, s, s, nb);
           const bool take = dist < best;  // (selects: see the vertex loop)
           best = take ? dist : best;
           found = found | take;
+          R nw[3];
+          mul_(RTB, nb, nw);
 #pragma unroll
           for (int j = 0; j < 3; j++) {
-            const R nj = -sg * pick3<R>(ax, RTB[3 * j], RTB[3 * j + 1], RTB[3 * j + 2]);
-            bn[j] = take ? nj : bn[j];
-            bpos[j] = take ? q[j] + wp[j] + nj * dist * (R)0.5 : bpos[j];
+            bn[j] = take ? -nw[j] : bn[j];
+            bpos[j] = take ? q[j] + wp[j] - nw[j] * dist * (R)0.5 : bpos[j];
           }
         }
       }
@@ -1193,14 +1341,34 @@ template <typename R, bool BLK> struct Sim {
     for (int i_ = 0; i_ < 8; i_++) { BRS_PIN(F.a0[i_]); BRS_PIN(f[i_]); }
     BRS_PIN(u[0]); BRS_PIN(u[1]); BRS_PIN(u[2]); BRS_PIN(zT);
     BRS_TOC(0);
-    BRS_TIC(1);
-    BRS_MARK("begin_collide_robot");
-    // collision: robot <-> floor.  Slot priority: wheel main points, torso corners, wheel triangle points
     F.nfr = 0; F.nfb = 0; F.nc = 0;
     F.pnfr = S.pnfr; F.pnfb = S.pnfb; F.pnc = S.pnc;
     F.sels = 0; F.psels = S.psels; F.pmR = S.pmR; F.pmX = S.pmX;
     F.muW = P.per_env_mu ? S.muw : P.cc[CC_WHEEL_FLOOR].mu;
     F.cDW = P.per_env_mu ? 2 * S.muw * S.muw * (1 + S.muw * S.muw) * P.tran_wheel : P.cc[CC_WHEEL_FLOOR].cD;
+    R uB[3] = {0, 0, 0}, zB = 0;
+    if constexpr (BLK) {
+      R qb[4] = {(R)S.bq[0], (R)S.bq[1], (R)S.bq[2], (R)S.bq[3]};
+      quat2mat_(qb, F.RB);
+      mulT_(F.RB, S.bv, uB);
+      zB = (R)(S.bp[2] - P.floor_z_d);
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        F.dTB[i] = (R)(S.p[i] - S.bp[i]);
+        F.a0[8 + i] = -P.g * F.nB()[i];
+        F.a0[11 + i] = 0;
+      }
+      // block <-> robot FIRST: its clipping parks candidates in the (still unused) robot<->floor slot region of the lane
+      BRS_TIC(3);
+      BRS_MARK("begin_collide_coupled");
+#ifndef BRS_NO_COUPLED
+      collide_coupled(P, st, F, S);
+#endif
+      BRS_TOC(3);
+    }
+    BRS_TIC(1);
+    BRS_MARK("begin_collide_robot");
+    // collision: robot <-> floor.  Slot priority: wheel main points, torso corners, wheel triangle points
     collide_wheel(P, st, F, u, S.w, S.ww, zT, 1, false);
     collide_wheel(P, st, F, u, S.w, S.ww, zT, 2, false);
     collide_torso(P, st, F, u, S.w, S.ww, zT);
@@ -1208,29 +1376,12 @@ template <typename R, bool BLK> struct Sim {
     collide_wheel(P, st, F, u, S.w, S.ww, zT, 2, true);
     BRS_TOC(1);
     if constexpr (BLK) {
-      R qb[4] = {(R)S.bq[0], (R)S.bq[1], (R)S.bq[2], (R)S.bq[3]};
-      quat2mat_(qb, F.RB);
-      R uB[3];
-      mulT_(F.RB, S.bv, uB);
-      R zB = (R)(S.bp[2] - P.floor_z_d);
-#pragma unroll
-      for (int i = 0; i < 3; i++) {
-        F.dTB[i] = (R)(S.p[i] - S.bp[i]);
-        F.a0[8 + i] = -P.g * F.nB()[i];
-        F.a0[11 + i] = 0;
-      }
       BRS_TIC(2);
       BRS_MARK("begin_collide_blockfloor");
 #ifndef BRS_NO_BLOCKFLOOR
       collide_block_floor(P, st, F, uB, S.bw, zB);
 #endif
       BRS_TOC(2);
-      BRS_TIC(3);
-      BRS_MARK("begin_collide_coupled");
-#ifndef BRS_NO_COUPLED
-      collide_coupled(P, st, F, S);
-#endif
-      BRS_TOC(3);
     }
     BRS_MARK("begin_tail");
     C.first = true; C.it = 0; C.cost = 0;
@@ -1241,6 +1392,7 @@ template <typename R, bool BLK> struct Sim {
       for (int i = 0; i < NV; i++) { S.a[i] = F.a0[i]; C.fcon[i] = 0; }
     }
     BRS_STAT(stats().last_iters[0] = 0; if (!C.conv) stats().solves[0]++);
+    BRS_STAT(stats().nfr_hist[F.nfr]++; stats().nfb_hist[F.nfb]++; stats().nc_hist[F.nc]++);
   }
   static BRS_HD void sub_iter(const Params<R>& P, Store<R>& st, ES& S, SubCtx& C) {
     C.conv = Solver::iterate(P, st, C.F, C.M, S.a, C.F.a0, C.fcon, C.first, C.it, C.cost);

@@ -407,171 +407,338 @@ static void plane_box(const model_t* m, const double* bpos, const double* bmat, 
   }
 }
 
-/* signed "max-axis" distance of point p (box frame) to a box and the outward axis that realises it */
-static double point_box(const double* p, const double* s, int* axis, double* sign) {
-  double best = -1e30;
-  *axis = 0; *sign = 1;
-  for (int k = 0; k < 3; k++) {
-    double d = fabs(p[k]) - s[k];
-    if (d > best) { best = d; *axis = k; *sign = p[k] >= 0 ? 1.0 : -1.0; }
+/* ---------------------------------------------------------------------------------------------------------------
+ * block <-> robot contact generation.  MuJoCo generates these with mjc_BoxBox (15-axis SAT, incident-face
+ * clipping, <= 8 points) and its general convex collider (box <-> cylinder, one point); neither is reproducible verbatim
+ * without the source, so this is the STANDARD clipped-polygon box-box (Gottschalk OBB SAT + Sutherland-Hodgman /
+ * Liang-Barsky clipping as in ODE's dBoxBox) and a closest-feature box <-> capped-cylinder test, written from their
+ * published descriptions.  PARITY WITH MUJOCO'S POINT SETS IS UNPINNED.  The HIP kernel (brs_core.hpp: collide_coupled)
+ * follows the same specification: same axis choice, same candidate enumeration order, same reduction to 4 points.
+ *
+ * box_box_points works in the frame of box T (half sizes sT), box B is a cube of half size s centred at cg with axes =
+ * columns of RTB.  Output: <= 4 contact points (T frame), their signed distances, the common normal T -> B.
+ * code: 0..2 T face, 3..5 B face, 6 + 3 i + j edge(T axis i) x edge(B axis j), -1 no contact.
+ * raw (optional): every valid candidate BEFORE the reduction to 4, as (x, y, z, dist) in the T frame.
+ * ------------------------------------------------------------------------------------------------------------- */
+#define BB_EDGE_REL 0.05
+#define BB_EDGE_ABS 1e-5
+#define BB_PAR_EPS 1e-6
+
+/* incident quad V[4] = (u, v, g) clipped against the rectangle |u| <= a, |v| <= b; candidates in FIXED order:
+ * 0..3 quad vertices inside, 4+2e / 5+2e entry / exit point of quad edge e, 12..15 rectangle corners inside the quad */
+static void clip_quad_rect(double V[4][3], double a, double b, double margin, double cand[16][3], int valid[16]) {
+  int inside[4];
+  for (int i = 0; i < 16; i++) valid[i] = 0;
+  for (int v = 0; v < 4; v++) {
+    inside[v] = fabs(V[v][0]) <= a && fabs(V[v][1]) <= b;
+    if (inside[v]) { memcpy(cand[v], V[v], 3 * sizeof(double)); valid[v] = 1; }
   }
-  return best;
+  for (int e = 0; e < 4; e++) {
+    const double* P0 = V[e]; const double* P1 = V[(e + 1) & 3];
+    double du = P1[0] - P0[0], dv = P1[1] - P0[1], dg = P1[2] - P0[2];
+    double t0 = 0, t1 = 1;
+    int ok = 1;
+    const double pp[4] = {-du, du, -dv, dv}, qq[4] = {P0[0] + a, a - P0[0], P0[1] + b, b - P0[1]};
+    for (int c = 0; c < 4; c++) {
+      if (pp[c] == 0) { if (qq[c] < 0) ok = 0; continue; }
+      double r = qq[c] / pp[c];
+      if (pp[c] < 0) { if (r > t0) t0 = r; } else { if (r < t1) t1 = r; }
+    }
+    if (!ok || !(t0 < t1)) continue;
+    if (!inside[e]) { cand[4 + 2 * e][0] = P0[0] + t0 * du; cand[4 + 2 * e][1] = P0[1] + t0 * dv; cand[4 + 2 * e][2] = P0[2] + t0 * dg; valid[4 + 2 * e] = 1; }
+    if (!inside[(e + 1) & 3]) { cand[5 + 2 * e][0] = P0[0] + t1 * du; cand[5 + 2 * e][1] = P0[1] + t1 * dv; cand[5 + 2 * e][2] = P0[2] + t1 * dg; valid[5 + 2 * e] = 1; }
+  }
+  /* rectangle corners inside the quad: corner = V0 + al (V1 - V0) + be (V3 - V0), 0 < al, be < 1 (the quad is a parallelogram) */
+  double e1u = V[1][0] - V[0][0], e1v = V[1][1] - V[0][1], e2u = V[3][0] - V[0][0], e2v = V[3][1] - V[0][1];
+  double det = e1u * e2v - e1v * e2u;
+  if (fabs(det) > 1e-30) {
+    double idet = 1.0 / det;
+    for (int c = 0; c < 4; c++) {
+      double cu = (c & 1) ? a : -a, cv = (c & 2) ? b : -b, ru = cu - V[0][0], rv = cv - V[0][1];
+      double al = (ru * e2v - rv * e2u) * idet, be = (e1u * rv - e1v * ru) * idet;
+      if (al > 0 && al < 1 && be > 0 && be < 1) {
+        cand[12 + c][0] = cu; cand[12 + c][1] = cv;
+        cand[12 + c][2] = V[0][2] + al * (V[1][2] - V[0][2]) + be * (V[3][2] - V[0][2]);
+        valid[12 + c] = 1;
+      }
+    }
+  }
+  for (int i = 0; i < 16; i++) if (valid[i] && !(cand[i][2] < margin)) valid[i] = 0;
 }
 
-/* OWN generator (not MuJoCo's mjc_BoxBox): separating-axis test over the 6 face axes, reference face = axis of
- * minimum overlap, contacts = vertices of the other box's incident face that lie behind the reference face
- * (dist < margin) and inside its rectangle (+margin); if none qualifies, the deepest incident vertex clamped into
- * the rectangle.  At most 4 points.  geom1 = torso, geom2 = block, normal from torso to block.
- * Worked in the torso-geom frame, as the HIP kernel does. */
-static void box_box_own(const model_t* m, const double* tpos, const double* tmat, const double* bpos, const double* bmat,
-                        const cparam* cp, bo_contact* con, int* n) {
-  double dw[3] = {bpos[0] - tpos[0], bpos[1] - tpos[1], bpos[2] - tpos[2]}, cg[3], RTB[9];
-  double rt = norm3(m->torso_size), rb = norm3(m->block_size), margin = cp->margin;
-  if (norm3(dw) > rt + rb + margin) return;
-  mulMatTVec3(cg, tmat, dw);
-  for (int i = 0; i < 3; i++)
-    for (int j = 0; j < 3; j++) RTB[3 * i + j] = tmat[i] * bmat[j] + tmat[3 + i] * bmat[3 + j] + tmat[6 + i] * bmat[6 + j];
-  const double* sT = m->torso_size;
-  double s = m->block_size[0];
-  double best = 1e30;
-  int bestax = -1;
-  for (int k = 0; k < 3; k++) { /* torso face axes */
-    double ext = s * (fabs(RTB[3 * k]) + fabs(RTB[3 * k + 1]) + fabs(RTB[3 * k + 2]));
-    double ov = sT[k] + ext - fabs(cg[k]);
-    if (ov < -margin) return;
-    if (ov < best) { best = ov; bestax = k; }
+int bo_box_box_points(const double* sT, double s, const double* cg, const double* RTB, double margin, double* pos /*[4][3]*/,
+                      double* dist /*[4]*/, double* nrm /*[3]*/, int* code, double* raw /*[16][4] or NULL*/, int* nraw) {
+  *code = -1;
+  if (nraw) *nraw = 0;
+  /* --- separating axes: 6 faces, 9 edge pairs; keep the axis of LARGEST separation (least penetration) */
+  double bestF = -1e300, bestE = -1e300;
+  int axF = -1, axE = -1;
+  for (int k = 0; k < 3; k++) {
+    double sep = fabs(cg[k]) - sT[k] - s * (fabs(RTB[3 * k]) + fabs(RTB[3 * k + 1]) + fabs(RTB[3 * k + 2]));
+    if (sep > margin) return 0;
+    if (sep > bestF) { bestF = sep; axF = k; }
   }
-  for (int j = 0; j < 3; j++) { /* block face axes */
+  for (int j = 0; j < 3; j++) {
     double dB = cg[0] * RTB[j] + cg[1] * RTB[3 + j] + cg[2] * RTB[6 + j];
-    double ext = sT[0] * fabs(RTB[j]) + sT[1] * fabs(RTB[3 + j]) + sT[2] * fabs(RTB[6 + j]);
-    double ov = s + ext - fabs(dB);
-    if (ov < -margin) return;
-    if (ov < best) { best = ov; bestax = 3 + j; }
+    double sep = fabs(dB) - s - (sT[0] * fabs(RTB[j]) + sT[1] * fabs(RTB[3 + j]) + sT[2] * fabs(RTB[6 + j]));
+    if (sep > margin) return 0;
+    if (sep > bestF) { bestF = sep; axF = 3 + j; }
   }
-  double cpos[4][3], cdist[4], nT[3];
-  int cnt = 0;
-  double fb_dist = 1e30, fb_pos[3] = {0, 0, 0};
-  if (bestax < 3) {
-    int k = bestax, j1 = (k + 1) % 3, j2 = (k + 2) % 3;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+      double len2 = 1.0 - RTB[3 * i + j] * RTB[3 * i + j];
+      if (len2 < BB_PAR_EPS) continue;
+      /* L = e_i x b_j ; L[i1] = -b_j[i2], L[i2] = b_j[i1] */
+      double cl = cg[i2] * RTB[3 * i1 + j] - cg[i1] * RTB[3 * i2 + j];
+      double rT = sT[i1] * fabs(RTB[3 * i2 + j]) + sT[i2] * fabs(RTB[3 * i1 + j]);
+      double rB = s * (fabs(RTB[3 * i + j1]) + fabs(RTB[3 * i + j2]));
+      double sep = (fabs(cl) - rT - rB) / sqrt(len2);
+      if (sep > margin) return 0;
+      if (sep > bestE) { bestE = sep; axE = 3 * i + j; }
+    }
+  int use_edge = axE >= 0 && bestE > bestF + BB_EDGE_REL * fabs(bestF) + BB_EDGE_ABS;
+  if (use_edge) {
+    int i = axE / 3, j = axE % 3, i1 = (i + 1) % 3, i2 = (i + 2) % 3;
+    double bj[3] = {RTB[j], RTB[3 + j], RTB[6 + j]}, L[3] = {0, 0, 0};
+    L[i1] = -bj[i2]; L[i2] = bj[i1];
+    double il = 1.0 / sqrt(1.0 - bj[i] * bj[i]);
+    for (int m = 0; m < 3; m++) L[m] *= il;
+    if (dot3(L, cg) < 0) for (int m = 0; m < 3; m++) L[m] = -L[m];
+    /* supporting edges: on T the edge along e_i extremal in +L, on B the edge along b_j extremal in -L */
+    double pA[3], pB[3] = {cg[0], cg[1], cg[2]};
+    for (int m = 0; m < 3; m++) pA[m] = m == i ? 0.0 : (L[m] >= 0 ? sT[m] : -sT[m]);
+    for (int m = 0; m < 3; m++) {
+      if (m == j) continue;
+      double bm[3] = {RTB[m], RTB[3 + m], RTB[6 + m]};
+      double sg = dot3(L, bm) >= 0 ? -s : s;
+      for (int c = 0; c < 3; c++) pB[c] += sg * bm[c];
+    }
+    /* closest points of the lines pA + al e_i and pB + be b_j, clamped to the edge extents */
+    double w[3] = {pA[0] - pB[0], pA[1] - pB[1], pA[2] - pB[2]};
+    double bdot = bj[i], dA = w[i], dBv = dot3(w, bj), den = 1.0 - bdot * bdot;
+    double al = (bdot * dBv - dA) / den, be = (dBv - bdot * dA) / den;
+    al = fmax(-sT[i], fmin(sT[i], al)); be = fmax(-s, fmin(s, be));
+    double qA[3] = {pA[0], pA[1], pA[2]}, qB[3];
+    qA[i] += al;
+    for (int c = 0; c < 3; c++) qB[c] = pB[c] + be * bj[c];
+    if (!(bestE < margin)) return 0;
+    for (int c = 0; c < 3; c++) { pos[c] = 0.5 * (qA[c] + qB[c]); nrm[c] = L[c]; }
+    dist[0] = bestE;
+    *code = 6 + axE;
+    if (raw) { raw[0] = pos[0]; raw[1] = pos[1]; raw[2] = pos[2]; raw[3] = bestE; *nraw = 1; }
+    return 1;
+  }
+  /* --- face contact: incident face of the other box clipped against the reference face */
+  double V[4][3], cand[16][3], a, b;
+  int valid[16];
+  double P3[16][3]; /* candidate contact positions, T frame */
+  if (axF < 3) {
+    int k = axF, j1 = (k + 1) % 3, j2 = (k + 2) % 3;
     double sg = cg[k] >= 0 ? 1.0 : -1.0;
-    nT[0] = nT[1] = nT[2] = 0; nT[k] = sg;
-    int js = 0; /* block axis most aligned with the reference normal */
+    nrm[0] = nrm[1] = nrm[2] = 0; nrm[k] = sg;
+    int js = 0;
     for (int j = 1; j < 3; j++) if (fabs(RTB[3 * k + j]) > fabs(RTB[3 * k + js])) js = j;
     double sj = -sg * (RTB[3 * k + js] >= 0 ? 1.0 : -1.0);
     int a1 = (js + 1) % 3, a2 = (js + 2) % 3;
+    static const int su[4] = {-1, 1, 1, -1}, sv[4] = {-1, -1, 1, 1}; /* around the face */
     for (int v = 0; v < 4; v++) {
       double loc[3], p[3];
-      loc[js] = sj * s; loc[a1] = (v & 1) ? s : -s; loc[a2] = (v & 2) ? s : -s;
+      loc[js] = sj * s; loc[a1] = su[v] * s; loc[a2] = sv[v] * s;
       mulMatVec3(p, RTB, loc);
-      for (int i = 0; i < 3; i++) p[i] += cg[i];
-      double dist = sg * p[k] - sT[k];
-      int lat = fabs(p[j1]) <= sT[j1] + margin && fabs(p[j2]) <= sT[j2] + margin;
-      if (dist < margin && lat) {
-        for (int i = 0; i < 3; i++) cpos[cnt][i] = p[i] - nT[i] * dist * 0.5;
-        cdist[cnt++] = dist;
-      }
-      if (dist < fb_dist) {
-        fb_dist = dist;
-        for (int i = 0; i < 3; i++) fb_pos[i] = p[i];
-        fb_pos[j1] = fmax(-sT[j1], fmin(sT[j1], fb_pos[j1]));
-        fb_pos[j2] = fmax(-sT[j2], fmin(sT[j2], fb_pos[j2]));
-      }
+      for (int c = 0; c < 3; c++) p[c] += cg[c];
+      V[v][0] = p[j1]; V[v][1] = p[j2]; V[v][2] = sg * p[k] - sT[k];
     }
-    if (cnt == 0 && fb_dist < margin) {
-      for (int i = 0; i < 3; i++) cpos[0][i] = fb_pos[i] - nT[i] * fb_dist * 0.5;
-      cdist[0] = fb_dist; cnt = 1;
+    a = sT[j1]; b = sT[j2];
+    clip_quad_rect(V, a, b, margin, cand, valid);
+    for (int c = 0; c < 16; c++) {
+      P3[c][j1] = cand[c][0]; P3[c][j2] = cand[c][1]; P3[c][k] = sg * (sT[k] + 0.5 * cand[c][2]);
     }
   } else {
-    int j = bestax - 3, i1 = (j + 1) % 3, i2 = (j + 2) % 3;
+    int j = axF - 3, i1 = (j + 1) % 3, i2 = (j + 2) % 3;
     double bj[3] = {RTB[j], RTB[3 + j], RTB[6 + j]};
-    double dB = dot3(cg, bj), sgB = dB >= 0 ? 1.0 : -1.0;
-    for (int i = 0; i < 3; i++) nT[i] = sgB * bj[i];
-    int ks = 0; /* torso axis most aligned with the reference normal */
+    double sgB = dot3(cg, bj) >= 0 ? 1.0 : -1.0;
+    for (int c = 0; c < 3; c++) nrm[c] = sgB * bj[c];
+    int ks = 0;
     for (int k = 1; k < 3; k++) if (fabs(bj[k]) > fabs(bj[ks])) ks = k;
     double sk = sgB * (bj[ks] >= 0 ? 1.0 : -1.0);
     int a1 = (ks + 1) % 3, a2 = (ks + 2) % 3;
+    static const int su[4] = {-1, 1, 1, -1}, sv[4] = {-1, -1, 1, 1};
     for (int v = 0; v < 4; v++) {
       double loc[3], rel[3], pB[3];
-      loc[ks] = sk * sT[ks]; loc[a1] = (v & 1) ? sT[a1] : -sT[a1]; loc[a2] = (v & 2) ? sT[a2] : -sT[a2];
-      for (int i = 0; i < 3; i++) rel[i] = loc[i] - cg[i];
+      loc[ks] = sk * sT[ks]; loc[a1] = su[v] * sT[a1]; loc[a2] = sv[v] * sT[a2];
+      for (int c = 0; c < 3; c++) rel[c] = loc[c] - cg[c];
       mulMatTVec3(pB, RTB, rel);
-      double dist = -sgB * pB[j] - s;
-      int lat = fabs(pB[i1]) <= s + margin && fabs(pB[i2]) <= s + margin;
-      if (dist < margin && lat) {
-        for (int i = 0; i < 3; i++) cpos[cnt][i] = loc[i] + nT[i] * dist * 0.5;
-        cdist[cnt++] = dist;
-      }
-      if (dist < fb_dist) {
-        double q[3] = {pB[0], pB[1], pB[2]}, back[3];
-        q[i1] = fmax(-s, fmin(s, q[i1])); q[i2] = fmax(-s, fmin(s, q[i2]));
-        mulMatVec3(back, RTB, q);
-        fb_dist = dist;
-        for (int i = 0; i < 3; i++) fb_pos[i] = back[i] + cg[i];
-      }
+      V[v][0] = pB[i1]; V[v][1] = pB[i2]; V[v][2] = -sgB * pB[j] - s;
     }
-    if (cnt == 0 && fb_dist < margin) {
-      for (int i = 0; i < 3; i++) cpos[0][i] = fb_pos[i] + nT[i] * fb_dist * 0.5;
-      cdist[0] = fb_dist; cnt = 1;
+    a = s; b = s;
+    clip_quad_rect(V, a, b, margin, cand, valid);
+    for (int c = 0; c < 16; c++) {
+      double q[3], back[3];
+      q[i1] = cand[c][0]; q[i2] = cand[c][1]; q[j] = -sgB * (s + 0.5 * cand[c][2]);
+      mulMatVec3(back, RTB, q);
+      for (int m = 0; m < 3; m++) P3[c][m] = back[m] + cg[m];
     }
   }
+  int cnt = 0;
+  for (int c = 0; c < 16; c++) cnt += valid[c];
+  if (raw) {
+    int r = 0;
+    for (int c = 0; c < 16; c++) if (valid[c]) { raw[4 * r] = P3[c][0]; raw[4 * r + 1] = P3[c][1]; raw[4 * r + 2] = P3[c][2]; raw[4 * r + 3] = cand[c][2]; r++; }
+    *nraw = r;
+  }
+  if (cnt == 0) return 0;
+  *code = axF;
+  if (cnt > 4) { /* reduction: keep the 4 deepest (ties: lower candidate index) */
+    int keep[16] = {0};
+    for (int pass = 0; pass < 4; pass++) {
+      double bd = 1e300; int bi = -1;
+      for (int c = 0; c < 16; c++) if (valid[c] && !keep[c] && cand[c][2] < bd) { bd = cand[c][2]; bi = c; }
+      keep[bi] = 1;
+    }
+    for (int c = 0; c < 16; c++) valid[c] = valid[c] && keep[c];
+  }
+  int n = 0;
+  for (int c = 0; c < 16; c++) if (valid[c]) { memcpy(pos + 3 * n, P3[c], 3 * sizeof(double)); dist[n] = cand[c][2]; n++; }
+  return n;
+}
+
+static void box_box(const model_t* m, const double* tpos, const double* tmat, const double* bpos, const double* bmat,
+                    const cparam* cp, bo_contact* con, int* n) {
+  double dw[3] = {bpos[0] - tpos[0], bpos[1] - tpos[1], bpos[2] - tpos[2]}, cg[3], RTB[9];
+  double rt = norm3(m->torso_size), rb = norm3(m->block_size);
+  if (norm3(dw) > rt + rb + cp->margin) return;
+  mulMatTVec3(cg, tmat, dw);
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) RTB[3 * i + j] = tmat[i] * bmat[j] + tmat[3 + i] * bmat[3 + j] + tmat[6 + i] * bmat[6 + j];
+  double pos[12], dist[4], nT[3];
+  int code, cnt = bo_box_box_points(m->torso_size, m->block_size[0], cg, RTB, cp->margin, pos, dist, nT, &code, NULL, NULL);
   for (int c = 0; c < cnt; c++) {
     double pw[3], nw[3];
-    mulMatVec3(pw, tmat, cpos[c]);
+    mulMatVec3(pw, tmat, pos + 3 * c);
     mulMatVec3(nw, tmat, nT);
     for (int i = 0; i < 3; i++) pw[i] += tpos[i];
-    add_contact(con, n, cdist[c], pw, nw, B_TORSO, B_BLOCK, cp);
+    add_contact(con, n, dist[c], pw, nw, B_TORSO, B_BLOCK, cp);
   }
 }
 
-/* OWN generator (MuJoCo: libccd, one point): deepest of {block vertices in cylinder, two cylinder surface
- * points nearest the block centre in the block}; geom1 = wheel, geom2 = block */
-static void box_cyl_own(const model_t* m, const double* wpos, const double* waxis, int wbody, const double* bpos,
-                        const double* bmat, const cparam* cp, bo_contact* con, int* n) {
-  double d[3] = {bpos[0] - wpos[0], bpos[1] - wpos[1], bpos[2] - wpos[2]};
-  double rw = sqrt(m->wheel_r * m->wheel_r + m->wheel_hl * m->wheel_hl), rb = norm3(m->block_size);
-  if (norm3(d) > rw + rb + cp->margin) return;
-  double best = cp->margin, bpos_c[3] = {0, 0, 0}, bn[3] = {0, 0, 1};
+/* signed distance of point p (cylinder frame: axis x, centre at the origin) to a capped cylinder, outward normal */
+static double point_cyl(const double* p, double r, double hl, double* nrm, int* okp) {
+  double rho = sqrt(p[1] * p[1] + p[2] * p[2]), drad = rho - r, dax = fabs(p[0]) - hl, sx = p[0] >= 0 ? 1.0 : -1.0;
+  *okp = 1;
+  if (drad > 0 && dax > 0) { /* rim region: Euclidean distance to the rim circle */
+    double dd = sqrt(drad * drad + dax * dax);
+    nrm[0] = sx * dax / dd; nrm[1] = drad * p[1] / (rho * dd); nrm[2] = drad * p[2] / (rho * dd);
+    return dd;
+  }
+  if (drad >= dax) {
+    if (rho < 1e-9) { *okp = 0; return 0; }
+    nrm[0] = 0; nrm[1] = p[1] / rho; nrm[2] = p[2] / rho;
+    return drad;
+  }
+  nrm[0] = sx; nrm[1] = 0; nrm[2] = 0;
+  return dax;
+}
+/* signed distance of point p (box frame) to a box (Euclidean outside, max-axis inside), outward normal */
+static double point_box(const double* p, const double* s, double* nrm) {
+  double q[3] = {fabs(p[0]) - s[0], fabs(p[1]) - s[1], fabs(p[2]) - s[2]};
+  if (q[0] > 0 || q[1] > 0 || q[2] > 0) {
+    double mv[3], dd;
+    for (int k = 0; k < 3; k++) mv[k] = q[k] > 0 ? (p[k] >= 0 ? q[k] : -q[k]) : 0.0;
+    dd = norm3(mv);
+    for (int k = 0; k < 3; k++) nrm[k] = mv[k] / dd;
+    return dd;
+  }
+  int ax = 0;
+  if (q[1] > q[ax]) ax = 1;
+  if (q[2] > q[ax]) ax = 2;
+  nrm[0] = nrm[1] = nrm[2] = 0; nrm[ax] = p[ax] >= 0 ? 1.0 : -1.0;
+  return q[ax];
+}
+
+/* wheel (capped cylinder, axis = torso x) <-> block: ONE point, the deepest of these closest-feature candidates, in this
+ * order (a later candidate replaces an earlier one only if strictly deeper):
+ *   (a) the 8 block vertices against the cylinder (exact point-cylinder distance),
+ *   (b) the 12 block edges against the barrel: point of the edge nearest the axis, if interior to the edge and within
+ *       the axial extent of the wheel,
+ *   (c) two cylinder surface points nearest the block centre (barrel point, rim point) against the box.
+ * Worked in the torso frame (as the HIP kernel does); d = block centre - wheel centre, RTB = block axes as columns. */
+int bo_box_cyl_point(const double* d, const double* RTB, double s, double r, double hl, double margin, double* pos, double* nrm,
+                     double* dist_out) {
+  double best = margin, bp[3] = {0, 0, 0}, bn[3] = {0, 0, 1};
   int found = 0;
   for (int i = 0; i < 8; i++) {
-    double loc[3] = {(i & 1) ? m->block_size[0] : -m->block_size[0], (i & 2) ? m->block_size[1] : -m->block_size[1],
-                     (i & 4) ? m->block_size[2] : -m->block_size[2]}, v[3];
-    mulMatVec3(v, bmat, loc);
-    for (int j = 0; j < 3; j++) v[j] += bpos[j];
-    double p[3] = {v[0] - wpos[0], v[1] - wpos[1], v[2] - wpos[2]};
-    double xi = dot3(p, waxis), rv[3] = {p[0] - xi * waxis[0], p[1] - xi * waxis[1], p[2] - xi * waxis[2]};
-    double rho = norm3(rv), drad = rho - m->wheel_r, dax = fabs(xi) - m->wheel_hl, dist, nrm[3];
-    if (drad >= dax) {
-      if (rho < 1e-9) continue;
-      dist = drad;
-      for (int j = 0; j < 3; j++) nrm[j] = rv[j] / rho;
-    } else {
-      dist = dax;
-      for (int j = 0; j < 3; j++) nrm[j] = (xi >= 0 ? 1.0 : -1.0) * waxis[j];
-    }
-    if (dist < best) {
+    double loc[3] = {(i & 1) ? s : -s, (i & 2) ? s : -s, (i & 4) ? s : -s}, v[3], nn[3];
+    mulMatVec3(v, RTB, loc);
+    for (int j = 0; j < 3; j++) v[j] += d[j];
+    int ok;
+    double dist = point_cyl(v, r, hl, nn, &ok);
+    if (ok && dist < best) {
       best = dist; found = 1;
-      for (int j = 0; j < 3; j++) { bn[j] = nrm[j]; bpos_c[j] = v[j] - nrm[j] * dist * 0.5; }
+      for (int j = 0; j < 3; j++) { bn[j] = nn[j]; bp[j] = v[j] - nn[j] * dist * 0.5; }
     }
   }
-  double xid = dot3(d, waxis), rd[3] = {d[0] - xid * waxis[0], d[1] - xid * waxis[1], d[2] - xid * waxis[2]};
-  double rho = norm3(rd);
-  if (rho > 1e-9) {
-    for (int cand = 0; cand < 2; cand++) {
-      double q[3], xc = xid > m->wheel_hl ? m->wheel_hl : (xid < -m->wheel_hl ? -m->wheel_hl : xid);
-      double rr = m->wheel_r;
-      if (cand == 1) { xc = (xid >= 0 ? 1.0 : -1.0) * m->wheel_hl; rr = rho < m->wheel_r ? rho : m->wheel_r; }
-      for (int j = 0; j < 3; j++) q[j] = wpos[j] + xc * waxis[j] + rr * rd[j] / rho;
-      double rel[3] = {q[0] - bpos[0], q[1] - bpos[1], q[2] - bpos[2]}, p[3], sg;
-      mulMatTVec3(p, bmat, rel);
-      int ax;
-      double dist = point_box(p, m->block_size, &ax, &sg);
+  for (int j = 0; j < 3; j++) {
+    int j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+    double dir[3] = {RTB[j], RTB[3 + j], RTB[6 + j]};
+    double dd = dir[1] * dir[1] + dir[2] * dir[2];
+    if (dd < 1e-8) continue;
+    for (int e = 0; e < 4; e++) {
+      double loc[3], o[3];
+      loc[j] = 0; loc[j1] = (e & 1) ? s : -s; loc[j2] = (e & 2) ? s : -s;
+      mulMatVec3(o, RTB, loc);
+      for (int c = 0; c < 3; c++) o[c] += d[c];
+      double tau = -(o[1] * dir[1] + o[2] * dir[2]) / dd;
+      if (!(fabs(tau) < s)) continue;
+      double p[3] = {o[0] + tau * dir[0], o[1] + tau * dir[1], o[2] + tau * dir[2]};
+      if (fabs(p[0]) > hl) continue;
+      double rho = sqrt(p[1] * p[1] + p[2] * p[2]);
+      if (rho < 1e-9) continue;
+      double dist = rho - r;
       if (dist < best) {
         best = dist; found = 1;
-        for (int j = 0; j < 3; j++) { bn[j] = -sg * bmat[3 * j + ax]; bpos_c[j] = q[j] + bn[j] * dist * 0.5; }
+        bn[0] = 0; bn[1] = p[1] / rho; bn[2] = p[2] / rho;
+        for (int c = 0; c < 3; c++) bp[c] = p[c] - bn[c] * dist * 0.5;
       }
     }
   }
-  if (found) add_contact(con, n, best, bpos_c, bn, wbody, B_BLOCK, cp);
+  double rho = sqrt(d[1] * d[1] + d[2] * d[2]);
+  if (rho > 1e-9) {
+    const double ss[3] = {s, s, s};
+    for (int cand = 0; cand < 2; cand++) {
+      double xc = d[0] > hl ? hl : (d[0] < -hl ? -hl : d[0]), rr = r;
+      if (cand == 1) { xc = d[0] >= 0 ? hl : -hl; rr = rho < r ? rho : r; }
+      double q[3] = {xc, rr * d[1] / rho, rr * d[2] / rho};
+      double rel[3] = {q[0] - d[0], q[1] - d[1], q[2] - d[2]}, p[3], nb[3], nw[3];
+      mulMatTVec3(p, RTB, rel);
+      double dist = point_box(p, ss, nb);
+      if (dist < best) {
+        best = dist; found = 1;
+        mulMatVec3(nw, RTB, nb);
+        for (int c = 0; c < 3; c++) { bn[c] = -nw[c]; bp[c] = q[c] + bn[c] * dist * 0.5; }
+      }
+    }
+  }
+  if (!found) return 0;
+  for (int c = 0; c < 3; c++) { pos[c] = bp[c]; nrm[c] = bn[c]; }
+  *dist_out = best;
+  return 1;
+}
+
+static void box_cyl(const model_t* m, const double* wpos, const double* tmat, int wbody, const double* bpos,
+                    const double* bmat, const cparam* cp, bo_contact* con, int* n) {
+  double dw[3] = {bpos[0] - wpos[0], bpos[1] - wpos[1], bpos[2] - wpos[2]}, d[3], RTB[9];
+  double rw = sqrt(m->wheel_r * m->wheel_r + m->wheel_hl * m->wheel_hl), rb = norm3(m->block_size);
+  if (norm3(dw) > rw + rb + cp->margin) return;
+  mulMatTVec3(d, tmat, dw);
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) RTB[3 * i + j] = tmat[i] * bmat[j] + tmat[3 + i] * bmat[3 + j] + tmat[6 + i] * bmat[6 + j];
+  double pos[3], nrm[3], dist, pw[3], nw[3];
+  if (!bo_box_cyl_point(d, RTB, m->block_size[0], m->wheel_r, m->wheel_hl, cp->margin, pos, nrm, &dist)) return;
+  mulMatVec3(pw, tmat, pos);
+  mulMatVec3(nw, tmat, nrm);
+  for (int i = 0; i < 3; i++) pw[i] += wpos[i];
+  add_contact(con, n, dist, pw, nw, wbody, B_BLOCK, cp);
 }
 
 static int collide(const model_t* m, const kin_t* k, bo_contact* con, double muw) {
@@ -590,11 +757,9 @@ static int collide(const model_t* m, const kin_t* k, bo_contact* con, double muw
   plane_box(m, gpos, k->xmat[B_TORSO], m->torso_size, B_TORSO, &m->cp_torso_floor, con, &n);
   if (m->has_block) {
     plane_box(m, k->xpos[B_BLOCK], k->xmat[B_BLOCK], m->block_size, B_BLOCK, &m->cp_block, con, &n);
-    box_box_own(m, gpos, k->xmat[B_TORSO], k->xpos[B_BLOCK], k->xmat[B_BLOCK], &m->cp_block, con, &n);
-    for (int w = 0; w < 2; w++) {
-      double ax[3] = {k->xmat[B_TORSO][0], k->xmat[B_TORSO][3], k->xmat[B_TORSO][6]}; /* cylinder axis = body x */
-      box_cyl_own(m, k->xpos[B_LW + w], ax, B_LW + w, k->xpos[B_BLOCK], k->xmat[B_BLOCK], &m->cp_block, con, &n);
-    }
+    box_box(m, gpos, k->xmat[B_TORSO], k->xpos[B_BLOCK], k->xmat[B_BLOCK], &m->cp_block, con, &n);
+    for (int w = 0; w < 2; w++) /* cylinder axis = torso body x: worked in the torso frame */
+      box_cyl(m, k->xpos[B_LW + w], k->xmat[B_TORSO], B_LW + w, k->xpos[B_BLOCK], k->xmat[B_BLOCK], &m->cp_block, con, &n);
   }
   return n;
 }

@@ -78,6 +78,9 @@ def lib():
         L.bo_script_remaining.argtypes = [vp, C.c_int]
         L.bo_stub_physics.argtypes = [vp, C.c_int, dp, dp, dp, dp]
         L.bo_pitch_yaw.argtypes = [dp, dp, dp]
+        ip = C.POINTER(C.c_int)
+        L.bo_box_box_points.argtypes = [dp, C.c_double, dp, dp, C.c_double, dp, dp, dp, ip, dp, ip]
+        L.bo_box_cyl_point.argtypes = [dp, dp, C.c_double, C.c_double, C.c_double, C.c_double, dp, dp, dp]
         L.bo_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.bo_uniform.restype = C.c_double
         L.bo_uniform.argtypes = [C.c_uint64, C.c_int64, C.c_uint32, C.c_int]
@@ -103,6 +106,27 @@ def pitch_yaw(xquat):
     p, y = C.c_double(), C.c_double()
     lib().bo_pitch_yaw(_dp(q), C.byref(p), C.byref(y))
     return p.value, y.value
+
+
+def box_box_points(sT, s, cg, RTB, margin):
+    """block<->torso generator on its own (torso-geom frame): (points[<=4,3], dists, normal, code, raw[<=16,4])"""
+    c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    sT, cg, RTB = c(sT), c(cg), c(RTB).reshape(9)
+    pos = np.zeros(12); dist = np.zeros(4); nrm = np.zeros(3); raw = np.zeros(64)
+    code, nraw = C.c_int(), C.c_int()
+    n = lib().bo_box_box_points(_dp(sT), float(s), _dp(cg), _dp(RTB), float(margin), _dp(pos), _dp(dist), _dp(nrm),
+                                C.byref(code), _dp(raw), C.byref(nraw))
+    return pos.reshape(4, 3)[:n].copy(), dist[:n].copy(), nrm, code.value, raw.reshape(16, 4)[:nraw.value].copy()
+
+
+def box_cyl_point(d, RTB, s, r, hl, margin):
+    """block<->wheel generator on its own (torso frame, wheel centre at the origin, axis x): (pos, normal, dist) or None"""
+    c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    d, RTB = c(d), c(RTB).reshape(9)
+    pos = np.zeros(3); nrm = np.zeros(3); dist = C.c_double()
+    if not lib().bo_box_cyl_point(_dp(d), _dp(RTB), float(s), float(r), float(hl), float(margin), _dp(pos), _dp(nrm), C.byref(dist)):
+        return None
+    return pos, nrm, dist.value
 
 
 def philox(ctr, key):

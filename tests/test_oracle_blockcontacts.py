@@ -1,8 +1,12 @@
-"""Geometric self-consistency of the project's OWN block<->robot contact generator (oracle/brs_oracle.c box_box_own /
-box_cyl_own; MuJoCo's mjc_BoxBox / libccd point sets are not reproducible here, so parity with MuJoCo is UNPINNED for
-these contacts -- DESIGN.md §2).  What can be pinned without MuJoCo is that every contact it emits is a geometrically
-valid one: orthonormal frame, a point between the two surfaces, a distance that moves one-to-one with a shift of the
-block along the normal (which also pins the normal's sign), and nothing at all when the bodies are apart."""
+"""Block<->robot contact generation: oracle/brs_oracle.c box_box / box_cyl.
+
+MuJoCo's own mjc_BoxBox / convex-collider point sets cannot be reproduced verbatim here (no source, not importable), so
+parity with MuJoCo is UNPINNED for these contacts.  What IS pinned:
+  * the generator against an independent brute-force numpy reference (tests/ref_boxbox.py: vertex-projection SAT over
+    the 15 axes, 3-D Sutherland-Hodgman clipping, alternating-projection box distance): same axis, same point set;
+  * geometry: orthonormal frame, every point between the two surfaces, distance one-to-one with a shift along the normal;
+  * no early contact (nothing beyond the margin, edge-edge poses included) and no missed contact;
+  * continuity of the contact patch while a vertex slides across the edge of the reference rectangle."""
 import numpy as np
 import pytest
 
@@ -59,7 +63,7 @@ def _place_near(rng, target):
 def test_emitted_contacts_are_geometrically_valid(target):
     rng = np.random.default_rng(100 + target)
     o = O.Oracle("Env03-v2", 1)
-    n_with = n_early = 0
+    n_with = 0
     for _ in range(400):
         c, bq = _place_near(rng, target)
         RB = _rot(bq)
@@ -76,22 +80,22 @@ def test_emitted_contacts_are_geometrically_valid(target):
             # the point sits between the two surfaces: within |dist|/2 (+ clamping slack) of each of them
             sd_b = _sd_box(RB.T @ (pos - c), np.full(3, BLOCK_S))
             sd_r = _sd_box(pos - TORSO_C, TORSO_S) if target == 1 else _sd_cyl_x(pos - WHEEL_P[target], WHEEL_R, WHEEL_HL)
-            slack = abs(dist) / 2 + 2.5e-3
-            ok = abs(sd_b) <= slack and abs(sd_r) <= slack
-            if not ok:
-                # known limit of the face-axis SAT (no edge-edge axes): in an edge-edge configuration the single
-                # "deepest vertex clamped into the reference rectangle" contact comes early, by up to ~1.5 cm
-                assert len([k for k in cons if k["body1"] == target]) == 1 and max(abs(sd_b), abs(sd_r)) < 0.015 + abs(dist), (sd_b, sd_r, dist)
-                n_early += 1
+            # between the two surfaces: each surface within |dist|/2 of the point along the normal; the slack covers
+            # points whose nearest surface point is not along the contact normal (rim / oblique incident face)
+            slack = abs(dist) / 2 + (1e-9 if target == 1 else 2.5e-3)
+            if target == 1:
+                # face / edge contacts: the point is never further than |dist|/2 from either surface
+                assert abs(sd_b) <= abs(dist) / 2 + 1e-9 and abs(sd_r) <= abs(dist) / 2 + 1e-9, (sd_b, sd_r, dist)
+            else:
+                assert abs(sd_b) <= slack and abs(sd_r) <= slack, (sd_b, sd_r, dist)
     assert n_with > 100, "the placement must actually produce contacts"
-    assert n_early <= 0.03 * n_with, (n_early, n_with)
 
 
 @pytest.mark.parametrize("target", [1, 2, 3])
 def test_distance_follows_a_shift_along_the_normal(target):
     rng = np.random.default_rng(200 + target)
     o = O.Oracle("Env03-v2", 1)
-    checked = jumps = 0
+    checked = 0
     for _ in range(300):
         c, bq = _place_near(rng, target)
         cons = [k for k in _contacts(o, c, bq) if k["body1"] == target]
@@ -105,18 +109,14 @@ def test_distance_follows_a_shift_along_the_normal(target):
         k1 = min(cons2, key=lambda k: k["dist"])
         if np.abs(k1["frame"][0] - k0["frame"][0]).max() > 1e-6 or len(cons2) != len(cons):
             continue   # the reference face / the contact set changed: not the same contact
-        if abs(k0["dist"] - k1["dist"]) > 1e-3:
-            # known discontinuity of the generator: a deep vertex laterally outside the reference rectangle is
-            # reported (clamped) only while no other vertex is inside the rectangle; when one enters, the deep one drops out
-            jumps += 1
-            continue
+        assert abs(k0["dist"] - k1["dist"]) < 1e-3, "the deepest point must not jump under a 20 um shift"
         dd = k0["dist"] - k1["dist"]
         if target == 1:
             assert abs(dd - eps) < 0.2 * eps, (k0["dist"], k1["dist"])      # face contacts: exactly one-to-one
         else:
             assert 0.3 * eps < dd < 1.2 * eps, (k0["dist"], k1["dist"])      # rim points slide along the rim: 0 < d' <= 1
         checked += 1
-    assert checked > 50 and jumps <= 0.05 * checked, (checked, jumps)
+    assert checked > 50
 
 
 def test_no_contacts_when_apart_and_some_when_overlapping():
@@ -163,3 +163,162 @@ def test_floor_contacts_of_wheels_and_torso_are_surface_points():
             assert abs(sd) < 1e-9, (con["body2"], sd)
             seen[con["body2"]] += 1
     assert min(seen.values()) > 20, seen
+
+
+# ------------------------------------------------------------------------------------------------ box-box vs reference
+from tests import ref_boxbox as RB  # noqa: E402
+
+
+def _random_pose(rng, spread=1.5):
+    """block centre 0.4 .. spread block sizes outside a random face / edge / corner region of the torso box"""
+    q = _quat(rng); R = _rot(q)
+    c = rng.uniform(-1, 1, 3) * TORSO_S
+    k = rng.integers(1, 4)  # how many coordinates are pushed outside: 1 face, 2 edge, 3 corner region
+    for ax in rng.permutation(3)[:k]:
+        c[ax] = rng.choice([-1.0, 1.0]) * (TORSO_S[ax] + BLOCK_S * rng.uniform(0.4, spread))
+    return c, R
+
+
+def _same_points(a, b, tol=1e-9):
+    if len(a) != len(b):
+        return False
+    used = set()
+    for p in a:
+        hit = [i for i, q in enumerate(b) if i not in used and np.abs(p - q).max() < tol]
+        if not hit:
+            return False
+        used.add(hit[0])
+    return True
+
+
+def test_box_box_matches_the_bruteforce_reference():
+    rng = np.random.default_rng(42)
+    kinds = {"T": 0, "B": 0, "E": 0}
+    many = none = 0
+    for _ in range(3000):
+        c, R = _random_pose(rng)
+        ref = RB.contacts(TORSO_S, BLOCK_S, c, R, MARGIN)
+        pos, dist, nrm, code, raw = O.box_box_points(TORSO_S, BLOCK_S, c, R, MARGIN)
+        if ref is None or len(ref["points"]) == 0:
+            assert len(pos) == 0, (c, code)
+            none += 1
+            continue
+        if ref["near_tie"]:
+            continue
+        exp_code = {"T": ref["index"], "B": 3 + ref["index"], "E": 6 + ref["index"]}[ref["kind"]]
+        assert code == exp_code, (code, exp_code, c)
+        np.testing.assert_allclose(nrm, ref["normal"], atol=1e-12)
+        assert _same_points(raw[:, :3], ref["points"]), (raw, ref["points"])
+        np.testing.assert_allclose(np.sort(raw[:, 3]), np.sort(ref["dists"]), atol=1e-12)
+        # reduction: at most 4, and they are the deepest of the full set
+        assert len(pos) == min(4, len(raw))
+        if len(raw) > 4:
+            many += 1
+            assert dist.max() <= np.sort(raw[:, 3])[3] + 1e-15
+        for p in pos:
+            assert any(np.abs(p - r[:3]).max() < 1e-12 for r in raw)
+        kinds[ref["kind"]] += 1
+    assert min(kinds.values()) > 30 and many > 10 and none > 100, (kinds, many, none)
+
+
+def test_box_box_no_early_and_no_missed_contact():
+    """a contact only if the boxes are closer than the margin (edge-edge and corner poses included: the face-axis-only
+    SAT of round 1 reported those up to 1.5 cm early), and always one when they overlap"""
+    rng = np.random.default_rng(7)
+    apart = touching = 0
+    for _ in range(600):
+        c, R = _random_pose(rng, spread=1.9)
+        d = RB.box_distance(TORSO_S, BLOCK_S, c, R)
+        pos, dist, nrm, code, raw = O.box_box_points(TORSO_S, BLOCK_S, c, R, MARGIN)
+        if d > MARGIN + 1e-6:
+            assert len(pos) == 0, (d, code, dist)
+            apart += 1
+        elif d < MARGIN - 1e-4:
+            assert len(pos) >= 1, (d, c)
+            # the deepest reported distance is the true separation when apart (edge-edge: exactly; face: <=)
+            if d > 1e-5:
+                assert dist.min() <= d + 1e-6 and dist.min() > d - 5e-4, (dist, d)
+            touching += 1
+    assert apart > 100 and touching > 100, (apart, touching)
+
+
+def test_box_box_edge_edge_pose_gives_one_point_at_the_true_distance():
+    """block edge (cube turned 45 degrees about z... and tipped) across the torso's vertical edge"""
+    c45 = np.sqrt(0.5)
+    Rz = np.array([[c45, -c45, 0], [c45, c45, 0], [0, 0, 1.0]])
+    th = np.radians(35)
+    Ry = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]])
+    R = Ry @ Rz
+    dirn = np.array([1.0, 1.0, 0.0]) / np.sqrt(2)
+    corner = np.array([TORSO_S[0], TORSO_S[1], 0.0])
+    for gap in (-0.001, 0.0005, 0.0015, 0.003, 0.01):
+        # support of the cube along -dirn gives where its nearest feature sits; place it `gap` off the torso edge
+        ext = BLOCK_S * np.abs(R.T @ dirn).sum()
+        c = corner + dirn * (ext + gap)
+        d = RB.box_distance(TORSO_S, BLOCK_S, c, R)
+        pos, dist, nrm, code, raw = O.box_box_points(TORSO_S, BLOCK_S, c, R, MARGIN)
+        if d >= MARGIN:
+            assert len(pos) == 0, (gap, d, dist)
+        else:
+            assert len(pos) == 1 and code >= 6, (gap, code, dist)
+            if d > 0:
+                assert abs(dist[0] - d) < 1e-6, (dist, d)
+            assert abs(np.linalg.norm(nrm) - 1) < 1e-12 and nrm @ c > 0
+
+
+def test_box_box_patch_is_continuous_while_a_vertex_crosses_the_rectangle_edge():
+    """slide a tilted block along the torso's front face past its side edge: the clipped contact patch (its deepest
+    distance and its centroid) moves continuously -- the round-1 generator dropped / clamped the outside vertex"""
+    th = np.radians(4.0)
+    Rx = np.array([[1, 0, 0], [0, np.cos(th), -np.sin(th)], [0, np.sin(th), np.cos(th)]])
+    Rzz = _rot(np.array([np.cos(0.01), 0, 0, np.sin(0.01)]))
+    a = np.radians(30.0)  # in-plane turn about the face normal: the vertices cross the rectangle edge one at a time
+    Ryy = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+    R = Rx @ Rzz @ Ryy
+    prev = None
+    counts = set()
+    for x in np.linspace(TORSO_S[0] - 0.035, TORSO_S[0] + 0.005, 400):
+        c = np.array([x, TORSO_S[1] + BLOCK_S * 0.85, 0.01])
+        pos, dist, nrm, code, raw = O.box_box_points(TORSO_S, BLOCK_S, c, R, MARGIN)
+        assert code == 1 and len(raw) >= 3, (x, code, len(raw))
+        counts.add(len(raw))
+        # centroid of the clipped polygon (area-weighted, from the raw points ordered by angle) and deepest distance
+        P = raw[:, [0, 2]]; ctr = P.mean(axis=0)
+        order = np.argsort(np.arctan2(P[:, 1] - ctr[1], P[:, 0] - ctr[0])); P = P[order]
+        x0, y0 = P[:, 0], P[:, 1]; x1, y1 = np.roll(x0, -1), np.roll(y0, -1)
+        cr = x0 * y1 - x1 * y0; area = cr.sum() / 2
+        cen = np.array([((x0 + x1) * cr).sum(), ((y0 + y1) * cr).sum()]) / (6 * area)
+        cur = (raw[:, 3].min(), cen, abs(area))
+        if prev is not None:
+            assert abs(cur[0] - prev[0]) < 2e-5, (x, cur[0], prev[0])
+            assert np.abs(cur[1] - prev[1]).max() < 2e-4, (x, cur[1], prev[1])
+            assert abs(cur[2] - prev[2]) < 2e-5, (x, cur[2], prev[2])
+        prev = cur
+    assert len(counts) >= 2, "the sweep must change the polygon's vertex count"
+
+
+def test_box_cyl_edge_on_barrel_and_vertex_cases():
+    """block edge resting across the wheel's barrel: ONE contact at the edge's closest point to the axis, at the true
+    radial distance (round 1 had only vertex and rim candidates there)"""
+    c45 = np.sqrt(0.5)
+    R = np.array([[c45, -c45, 0], [c45, c45, 0], [0, 0, 1.0]]) @ np.array([[1, 0, 0], [0, c45, -c45], [0, c45, c45]])
+    # which block edge is lowest along -z?  brute force the true distance by sampling all 12 edges
+    def true_dist(d):
+        best = 1e9
+        for j in range(3):
+            for su in (-1, 1):
+                for sv in (-1, 1):
+                    o = np.zeros(3); o[(j + 1) % 3] = su * BLOCK_S; o[(j + 2) % 3] = sv * BLOCK_S
+                    for t in np.linspace(-BLOCK_S, BLOCK_S, 2001):
+                        loc = o.copy(); loc[j] = t
+                        best = min(best, _sd_cyl_x(R @ loc + d, WHEEL_R, WHEEL_HL))
+        return best
+    for gap in (-0.002, 0.0005, 0.0015):
+        ext = BLOCK_S * np.abs(R.T @ np.array([0, 0, -1.0])).sum()
+        d = np.array([0.002, 0.0, WHEEL_R + ext + gap])
+        got = O.box_cyl_point(d, R, BLOCK_S, WHEEL_R, WHEEL_HL, MARGIN)
+        td = true_dist(d)
+        assert got is not None and abs(got[2] - td) < 2e-6, (gap, got, td)
+        pos, nrm, dist = got
+        assert abs(np.linalg.norm(nrm) - 1) < 1e-12 and nrm[2] > 0.9
+    assert O.box_cyl_point(np.array([0.0, 0.0, WHEEL_R + 0.05]), R, BLOCK_S, WHEEL_R, WHEEL_HL, MARGIN) is None
