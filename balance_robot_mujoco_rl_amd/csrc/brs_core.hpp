@@ -27,7 +27,7 @@
 #endif
 
 #if defined(BRS_MARKERS) && defined(__HIP_DEVICE_COMPILE__)
-#define BRS_MARK(name) asm volatile("; BRS_MARK " name)
+#define BRS_MARK(name) do { __builtin_amdgcn_sched_barrier(0); asm volatile("; BRS_MARK " name); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define BRS_MARK(name) do { } while (0)
 #endif
@@ -651,6 +651,7 @@ template <typename R, bool BLK> struct Sim {
     R cg[3] = {cB[0], cB[1], cB[2] - P.torso_cz};  // block centre relative to the torso geom centre
     R dd2 = dot_(cg, cg), rr0 = P.torso_brad + P.block_brad + c.margin;
     if (dd2 <= rr0 * rr0) {
+      BRS_MARK("cc_sat");
       const R sT[3] = {P.torso_sx, P.torso_sy, P.torso_sz};
       R Q[9];
 #pragma unroll
@@ -689,6 +690,7 @@ template <typename R, bool BLK> struct Sim {
         }
       }
       if (!sep) {
+        BRS_MARK("cc_branch");
         const bool use_edge = (axE >= 0) & (bestE > bestF + (R)0.05 * abs_(bestF) + (R)1e-5);
         if (use_edge) {
           if (bestE < c.margin) {
@@ -732,6 +734,7 @@ template <typename R, bool BLK> struct Sim {
           // face case.  Reference frame coordinates (u, v, g): u, v span the reference rectangle |u| <= ra, |v| <= rb, g is
           // the signed distance to the reference face.  Incident face = centre Cc +- H1 +- H2 in those coordinates; a
           // candidate (u, v, g) maps back to the torso geom frame as  pos = u A1 + v A2 + (half + g/2) A3 + A0.
+          BRS_MARK("cc_face_setup");
           R Cc[3], H1[3], H2[3], A0[3], A1[3], A2[3], A3[3], nrm[3], ra, rb, half;
           if (axF < 3) {
             const int k = axF, j1 = k == 2 ? 0 : k + 1, j2 = k == 0 ? 2 : k - 1;
@@ -780,6 +783,7 @@ template <typename R, bool BLK> struct Sim {
 #pragma unroll
             for (int m = 0; m < 3; m++) { A0[m] = cg[m]; A1[m] = bi1[m]; A2[m] = bi2[m]; A3[m] = -sgB * bj[m]; nrm[m] = sgB * bj[m]; }
           }
+          BRS_MARK("cc_clip");
           // incident quad, in order around the face
           R V[4][3];
 #pragma unroll
@@ -787,15 +791,15 @@ template <typename R, bool BLK> struct Sim {
             V[0][q] = Cc[q] - H1[q] - H2[q]; V[1][q] = Cc[q] + H1[q] - H2[q];
             V[2][q] = Cc[q] + H1[q] + H2[q]; V[3][q] = Cc[q] - H1[q] + H2[q];
           }
-          R* scr = st.base + (SLOT_ROBOT * SLOT_WORDS) * st.stride;  // 48 words of scratch: candidate c at words 3c .. 3c+2
+          // the <= 16 clip candidates (u, v, g) stay in registers (static indices); `vmask` = the valid ones
+          R cu_[16], cv_[16], gq[16];
           uint32_t vmask = 0;
           bool ins[4];
 #pragma unroll
           for (int v = 0; v < 4; v++) {
             ins[v] = (abs_(V[v][0]) <= ra) & (abs_(V[v][1]) <= rb);
             vmask |= (ins[v] & (V[v][2] < c.margin)) ? (1u << v) : 0u;
-#pragma unroll
-            for (int q = 0; q < 3; q++) scr[(3 * v + q) * st.stride] = V[v][q];
+            cu_[v] = V[v][0]; cv_[v] = V[v][1]; gq[v] = V[v][2];
           }
 #pragma unroll
           for (int e = 0; e < 4; e++) {
@@ -817,10 +821,8 @@ template <typename R, bool BLK> struct Sim {
             const R g0 = V[e][2] + t0 * dg, g1 = V[e][2] + t1 * dg;
             vmask |= (ok & !ins[e] & (g0 < c.margin)) ? (1u << (4 + 2 * e)) : 0u;
             vmask |= (ok & !ins[e1] & (g1 < c.margin)) ? (1u << (5 + 2 * e)) : 0u;
-            scr[(3 * (4 + 2 * e) + 0) * st.stride] = V[e][0] + t0 * du; scr[(3 * (4 + 2 * e) + 1) * st.stride] = V[e][1] + t0 * dv;
-            scr[(3 * (4 + 2 * e) + 2) * st.stride] = g0;
-            scr[(3 * (5 + 2 * e) + 0) * st.stride] = V[e][0] + t1 * du; scr[(3 * (5 + 2 * e) + 1) * st.stride] = V[e][1] + t1 * dv;
-            scr[(3 * (5 + 2 * e) + 2) * st.stride] = g1;
+            cu_[4 + 2 * e] = V[e][0] + t0 * du; cv_[4 + 2 * e] = V[e][1] + t0 * dv; gq[4 + 2 * e] = g0;
+            cu_[5 + 2 * e] = V[e][0] + t1 * du; cv_[5 + 2 * e] = V[e][1] + t1 * dv; gq[5 + 2 * e] = g1;
           }
           {  // rectangle corners inside the incident parallelogram: corner = V0 + al (V1 - V0) + be (V3 - V0)
             const R e1u = 2 * H1[0], e1v = 2 * H1[1], e2u = 2 * H2[0], e2v = 2 * H2[1];
@@ -834,44 +836,79 @@ template <typename R, bool BLK> struct Sim {
               const R g = V[0][2] + al * (2 * H1[2]) + be * (2 * H2[2]);
               const bool in = dok & (al > 0) & (al < 1) & (be > 0) & (be < 1);
               vmask |= (in & (g < c.margin)) ? (1u << (12 + q)) : 0u;
-              scr[(3 * (12 + q) + 0) * st.stride] = cu; scr[(3 * (12 + q) + 1) * st.stride] = cv; scr[(3 * (12 + q) + 2) * st.stride] = g;
+              cu_[12 + q] = cu; cv_[12 + q] = cv; gq[12 + q] = g;
             }
           }
-          int cnt = 0;
+          BRS_MARK("cc_reduce");
+          // keep the 4 deepest (ties: lower candidate index).  tau = 4th smallest valid g from a pruned sorting network
+          // (sorted groups of 4, bitonic half-merges keeping the low half) -- branch-free: some lane of a wave needs it on
+          // most trips, and a per-lane selection loop would cost every lane its worst case
+          uint32_t keep = vmask;
+          {
+            R k_[16];
 #pragma unroll
-          for (int q = 0; q < 16; q++) cnt += (int)((vmask >> q) & 1u);
-          if (cnt > 4) {  // rare: keep the 4 deepest (ties: lower candidate index)
-            uint32_t keep = 0;
-            for (int pass = 0; pass < 4; pass++) {
-              R bd = (R)1e30;
-              int bi = 0;
-              for (int q = 0; q < 16; q++) {
-                const R g = scr[(3 * q + 2) * st.stride];
-                const bool take = (((vmask & ~keep) >> q) & 1u) && g < bd;
-                bd = take ? g : bd; bi = take ? q : bi;
-              }
-              keep |= 1u << bi;
+            for (int q = 0; q < 16; q++) k_[q] = ((vmask >> q) & 1u) ? gq[q] : (R)1e30;
+#define BRS_CSWAP(a, b) { const R lo_ = min_(k_[a], k_[b]), hi_ = max_(k_[a], k_[b]); k_[a] = lo_; k_[b] = hi_; }
+#pragma unroll
+            for (int g4 = 0; g4 < 16; g4 += 4) {
+              BRS_CSWAP(g4 + 0, g4 + 1); BRS_CSWAP(g4 + 2, g4 + 3); BRS_CSWAP(g4 + 0, g4 + 2); BRS_CSWAP(g4 + 1, g4 + 3); BRS_CSWAP(g4 + 1, g4 + 2);
             }
-            vmask = keep;
+            // merge (0..3, 4..7) -> 0..3 ; (8..11, 12..15) -> 8..11 ; then (0..3, 8..11) -> 0..3  (low halves, re-sorted)
+#pragma unroll
+            for (int m = 0; m < 3; m++) {
+              const int A = m == 1 ? 8 : 0, B = m == 0 ? 4 : (m == 1 ? 12 : 8);
+#pragma unroll
+              for (int q = 0; q < 4; q++) k_[A + q] = min_(k_[A + q], k_[B + 3 - q]);
+              BRS_CSWAP(A + 0, A + 2); BRS_CSWAP(A + 1, A + 3); BRS_CSWAP(A + 0, A + 1); BRS_CSWAP(A + 2, A + 3);
+            }
+#undef BRS_CSWAP
+            const R tau = k_[3];
+            uint32_t lt = 0, eq = 0;
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+              const bool vq = ((vmask >> q) & 1u) != 0;
+              lt |= (vq & (gq[q] < tau)) ? (1u << q) : 0u;
+              eq |= (vq & (gq[q] == tau)) ? (1u << q) : 0u;
+            }
+            int need = 4 - (int)__builtin_popcount(lt);
+            uint32_t kp = lt;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+              const bool go = (t < need) & (eq != 0u);
+              const uint32_t lowbit = eq & (0u - eq);
+              kp |= go ? lowbit : 0u;
+              eq &= go ? ~lowbit : ~0u;
+            }
+            keep = __builtin_popcount(vmask) > 4 ? kp : vmask;
           }
-          if (vmask) {
+          BRS_MARK("cc_scatter");
+          const int nkeep = (int)__builtin_popcount(keep);
+          // compaction through the lane's LDS column: kept candidate with rank r -> scratch words 3r .. 3r+2 of the (not yet
+          // written) robot<->floor slot region, everything else -> a dump slot; the insertion loop then reads by rank
+          R* scr = st.base + (SLOT_ROBOT * SLOT_WORDS) * st.stride;
+#pragma unroll
+          for (int q = 0; q < 16; q++) {
+            const bool kq = ((keep >> q) & 1u) != 0;
+            const int rank = (int)__builtin_popcount(keep & ((1u << q) - 1u));
+            R* dst = scr + (3 * (kq ? rank : 4)) * st.stride;
+            dst[0] = cu_[q]; dst[st.stride] = cv_[q]; dst[2 * st.stride] = gq[q];
+          }
+          BRS_MARK("cc_insert");
+          if (nkeep > 0) {
             R fw[9];
             world_frame(F, nrm, fw);  // one contact frame for the whole patch
-            bool first_in_patch = true;
-            while (vmask) {
-              const int q = __builtin_ctz(vmask);
-              vmask &= vmask - 1u;
-              const R u = scr[(3 * q) * st.stride], v = scr[(3 * q + 1) * st.stride], g = scr[(3 * q + 2) * st.stride];
+            for (int r = 0; r < nkeep; r++) {
+              const R u = scr[(3 * r) * st.stride], v = scr[(3 * r + 1) * st.stride], g = scr[(3 * r + 2) * st.stride];
               const R wv = half + (R)0.5 * g;
               R pos[3] = {A0[0] + u * A1[0] + v * A2[0] + wv * A3[0], A0[1] + u * A1[1] + v * A2[1] + wv * A3[1],
                           A0[2] + u * A1[2] + v * A2[2] + wv * A3[2] + P.torso_cz};
-              add_coupled(P, st, F, S, pos, fw, g, 0, !first_in_patch);
-              first_in_patch = false;
+              add_coupled(P, st, F, S, pos, fw, g, 0, r > 0);
             }
           }
         }
       }
     }
+    BRS_MARK("cc_wheels");
     BRS_TOC(10);
     BRS_TIC(11);
     // (ii) wheel cylinder <-> block box: ONE point per wheel, the deepest of the closest-feature candidates (a) block
@@ -883,55 +920,63 @@ template <typename R, bool BLK> struct Sim {
       R d[3] = {cB[0] - wp[0], cB[1] - wp[1], cB[2] - wp[2]};
       R rr = P.wheel_brad + P.block_brad + c.margin;
       if (dot_(d, d) > rr * rr) continue;
-      R best = c.margin, bpos[3] = {0, 0, 0}, bn[3] = {0, 0, 1};
+      R best = c.margin, bpos[3] = {0, 0, 0}, bn[3] = {0, 0, 1}, wq[3] = {0, 0, 0};
       bool found = false;
+      // (a) + (b): block points against the cylinder -- only the winning POINT is tracked in the loops (4 selects per
+      // candidate); its normal and contact position are rebuilt once afterwards
+      const R sb[3][3] = {{s * RTB[0], s * RTB[3], s * RTB[6]}, {s * RTB[1], s * RTB[4], s * RTB[7]}, {s * RTB[2], s * RTB[5], s * RTB[8]}};
+      auto sd_cyl = [&](const R* p, R& rho2) {
+        rho2 = p[1] * p[1] + p[2] * p[2];
+        const R rho = sqrt_(rho2), drad = rho - P.wheel_r, dax = abs_(p[0]) - P.wheel_hl;
+        const bool rim = (drad > 0) & (dax > 0);
+        const R drim = sqrt_(drad * drad + dax * dax);
+        return rim ? drim : max_(drad, dax);
+      };
 #pragma unroll
       for (int i = 0; i < 8; i++) {
-        R loc[3] = {(i & 1) ? s : -s, (i & 2) ? s : -s, (i & 4) ? s : -s}, v[3];
-        mul_(RTB, loc, v);
-        R p[3] = {v[0] + d[0], v[1] + d[1], v[2] + d[2]};  // vertex relative to the wheel centre; axis = x
-        // branch-free on purpose: 8 vertices x 2 wheels of two-sided branches cost more than the selects
-        R xi = p[0], rho = sqrt_(p[1] * p[1] + p[2] * p[2]);
-        R drad = rho - P.wheel_r, dax = abs_(xi) - P.wheel_hl;
-        const bool rim = (drad > 0) & (dax > 0);
-        const bool radial = drad >= dax;
-        const R ir = rcp_(max_(rho, (R)1e-9));
-        const R drim = sqrt_(drad * drad + dax * dax), idr = rcp_(max_(drim, (R)1e-20));
-        const R dist = rim ? drim : (radial ? drad : dax);
-        const R sx = xi >= 0 ? (R)1 : (R)-1;
-        const R kx = rim ? dax * idr : (radial ? (R)0 : (R)1), kr = rim ? drad * idr : (radial ? (R)1 : (R)0);
-        const R nrm[3] = {sx * kx, kr * p[1] * ir, kr * p[2] * ir};
-        const bool take = (rim | !radial | (rho >= (R)1e-9)) & (dist < best);
+        R p[3];
+#pragma unroll
+        for (int q = 0; q < 3; q++) p[q] = d[q] + ((i & 1) ? sb[0][q] : -sb[0][q]) + ((i & 2) ? sb[1][q] : -sb[1][q]) + ((i & 4) ? sb[2][q] : -sb[2][q]);
+        R rho2;
+        const R dist = sd_cyl(p, rho2);
+        const bool take = !(rho2 < (R)1e-18) & (dist < best);
         best = take ? dist : best;
         found = found | take;
 #pragma unroll
-        for (int j = 0; j < 3; j++) { bn[j] = take ? nrm[j] : bn[j]; bpos[j] = take ? p[j] + wp[j] - nrm[j] * dist * (R)0.5 : bpos[j]; }
+        for (int q = 0; q < 3; q++) wq[q] = take ? p[q] : wq[q];
       }
 #pragma unroll
       for (int j = 0; j < 3; j++) {
         const int j1 = (j + 1) % 3, j2 = (j + 2) % 3;
         const R dir[3] = {RTB[j], RTB[3 + j], RTB[6 + j]};
         const R dd = dir[1] * dir[1] + dir[2] * dir[2];
-        const bool dok = dd >= (R)1e-8;
+        const bool dok = !(dd < (R)1e-8);
         const R idd = rcp_(dok ? dd : (R)1);
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-          R loc[3];
-          loc[j] = 0; loc[j1] = (e & 1) ? s : -s; loc[j2] = (e & 2) ? s : -s;
           R o[3];
-          mul_(RTB, loc, o);
-          o[0] += d[0]; o[1] += d[1]; o[2] += d[2];
+#pragma unroll
+          for (int q = 0; q < 3; q++) o[q] = d[q] + ((e & 1) ? sb[j1][q] : -sb[j1][q]) + ((e & 2) ? sb[j2][q] : -sb[j2][q]);
           const R tau = -(o[1] * dir[1] + o[2] * dir[2]) * idd;
           const R p[3] = {o[0] + tau * dir[0], o[1] + tau * dir[1], o[2] + tau * dir[2]};
-          const R rho = sqrt_(p[1] * p[1] + p[2] * p[2]), ir = rcp_(max_(rho, (R)1e-9));
-          const R dist = rho - P.wheel_r;
-          const bool take = dok & (abs_(tau) < s) & !(abs_(p[0]) > P.wheel_hl) & !(rho < (R)1e-9) & (dist < best);
+          R rho2;
+          const R dist = sd_cyl(p, rho2);
+          const bool take = dok & (abs_(tau) < s) & !(rho2 < (R)1e-18) & (dist < best);
           best = take ? dist : best;
           found = found | take;
-          const R nrm[3] = {(R)0, p[1] * ir, p[2] * ir};
 #pragma unroll
-          for (int q = 0; q < 3; q++) { bn[q] = take ? nrm[q] : bn[q]; bpos[q] = take ? p[q] + wp[q] - nrm[q] * dist * (R)0.5 : bpos[q]; }
+          for (int q = 0; q < 3; q++) wq[q] = take ? p[q] : wq[q];
         }
+      }
+      {  // normal of the cylinder at the winning point (the point-cylinder rule of the oracle's point_cyl)
+        const R rho = sqrt_(wq[1] * wq[1] + wq[2] * wq[2]), drad = rho - P.wheel_r, dax = abs_(wq[0]) - P.wheel_hl;
+        const bool rim = (drad > 0) & (dax > 0), radial = drad >= dax;
+        const R ir = rcp_(max_(rho, (R)1e-9)), idr = rcp_(max_(sqrt_(drad * drad + dax * dax), (R)1e-20));
+        const R sx = wq[0] >= 0 ? (R)1 : (R)-1;
+        const R kx = rim ? dax * idr : (radial ? (R)0 : (R)1), kr = rim ? drad * idr : (radial ? (R)1 : (R)0);
+        bn[0] = sx * kx; bn[1] = kr * wq[1] * ir; bn[2] = kr * wq[2] * ir;
+#pragma unroll
+        for (int q = 0; q < 3; q++) bpos[q] = wq[q] + wp[q] - bn[q] * best * (R)0.5;
       }
       R xid = d[0], rho = sqrt_(d[1] * d[1] + d[2] * d[2]);
       if (rho > (R)1e-9) {

@@ -48,11 +48,16 @@ class BatchedSim:
         self.nq, self.nv = nq.value, nv.value
         self.max_episode_steps = max_episode_steps or self.spec.max_episode_steps
         d = self.device
-        self.obs = torch.zeros((self.n, 6), dtype=torch.float32, device=d)
-        self.terminal_obs = torch.zeros((self.n, 6), dtype=torch.float32, device=d)
-        self.reward = torch.zeros(self.n, dtype=torch.float32, device=d)
-        self.terminated = torch.zeros(self.n, dtype=torch.uint8, device=d)
-        self.truncated = torch.zeros(self.n, dtype=torch.uint8, device=d)
+        # step outputs live in ONE device allocation [obs 24n | terminal_obs 24n | reward 4n | terminated n | truncated n]
+        # so that a host consumer (BalanceVecEnv) fetches them with a single D2H copy into a pinned mirror
+        n = self.n
+        self._packed = torch.zeros(54 * n, dtype=torch.uint8, device=d)
+        self.obs = self._packed[0:24 * n].view(torch.float32).view(n, 6)
+        self.terminal_obs = self._packed[24 * n:48 * n].view(torch.float32).view(n, 6)
+        self.reward = self._packed[48 * n:52 * n].view(torch.float32)
+        self.terminated = self._packed[52 * n:53 * n]
+        self.truncated = self._packed[53 * n:54 * n]
+        self._host = None  # pinned staging, allocated on first host-side use
 
     # ------------------------------------------------------------------ lifecycle
     def close(self):
@@ -94,6 +99,45 @@ class BatchedSim:
                                     C.c_void_p(self.truncated.data_ptr()), C.c_void_p(self.terminal_obs.data_ptr()),
                                     self._stream()), "brs_step")
         return self.obs, self.reward, self.terminated, self.truncated, self.terminal_obs
+
+    # ------------------------------------------------------------------ host-side consumers (numpy in / numpy out)
+    def _host_buffers(self):
+        if self._host is None:
+            n = self.n
+            self._host = dict(out=torch.empty(54 * n, dtype=torch.uint8, pin_memory=True),
+                              act=torch.empty((n, 2), dtype=torch.float32, pin_memory=True),
+                              act_dev=torch.empty((n, 2), dtype=torch.float32, device=self.device),
+                              done=torch.cuda.Event())
+            o = self._host["out"].numpy()
+            self._host["views"] = (o[0:24 * n].view(np.float32).reshape(n, 6), o[24 * n:48 * n].view(np.float32).reshape(n, 6),
+                                   o[48 * n:52 * n].view(np.float32), o[52 * n:53 * n], o[53 * n:54 * n])
+            self._host["act_np"] = self._host["act"].numpy()
+        return self._host
+
+    def step_host_async(self, actions_np):
+        """numpy actions -> pinned staging -> async H2D, kernel, ONE async D2H of the packed outputs, all on the current
+        stream; nothing blocks.  Pair with step_host_wait()."""
+        hb = self._host_buffers()
+        np.copyto(hb["act_np"], actions_np, casting="same_kind")
+        hb["act_dev"].copy_(hb["act"], non_blocking=True)
+        self.step(hb["act_dev"])
+        hb["out"].copy_(self._packed, non_blocking=True)
+        hb["done"].record(torch.cuda.current_stream(self.device))
+
+    def step_host_wait(self):
+        """-> (obs, terminal_obs, reward, terminated, truncated) numpy VIEWS of the pinned staging buffer (valid until the
+        next step_host_async of this object)"""
+        hb = self._host_buffers()
+        hb["done"].synchronize()
+        return hb["views"]
+
+    def reset_host(self):
+        hb = self._host_buffers()
+        self.reset()
+        hb["out"].copy_(self._packed, non_blocking=True)
+        hb["done"].record(torch.cuda.current_stream(self.device))
+        hb["done"].synchronize()
+        return hb["views"][0]
 
     def physics(self, ctrl, nsub):
         c = torch.as_tensor(ctrl, dtype=torch.float32, device=self.device).contiguous()

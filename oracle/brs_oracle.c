@@ -658,25 +658,23 @@ static double point_box(const double* p, const double* s, double* nrm) {
 
 /* wheel (capped cylinder, axis = torso x) <-> block: ONE point, the deepest of these closest-feature candidates, in this
  * order (a later candidate replaces an earlier one only if strictly deeper):
- *   (a) the 8 block vertices against the cylinder (exact point-cylinder distance),
- *   (b) the 12 block edges against the barrel: point of the edge nearest the axis, if interior to the edge and within
- *       the axial extent of the wheel,
+ *   (a) the 8 block vertices and (b) on each of the 12 block edges the point nearest the cylinder axis (if interior to the
+ *       edge), each evaluated as a POINT against the cylinder (exact point-cylinder distance; points on the axis skipped);
+ *       the normal is the cylinder's outward normal at the winning point;
  *   (c) two cylinder surface points nearest the block centre (barrel point, rim point) against the box.
  * Worked in the torso frame (as the HIP kernel does); d = block centre - wheel centre, RTB = block axes as columns. */
 int bo_box_cyl_point(const double* d, const double* RTB, double s, double r, double hl, double margin, double* pos, double* nrm,
                      double* dist_out) {
-  double best = margin, bp[3] = {0, 0, 0}, bn[3] = {0, 0, 1};
-  int found = 0;
+  double best = margin, wp[3] = {0, 0, 0}, bp[3] = {0, 0, 0}, bn[3] = {0, 0, 1};
+  int found = 0, from_c = 0;
   for (int i = 0; i < 8; i++) {
     double loc[3] = {(i & 1) ? s : -s, (i & 2) ? s : -s, (i & 4) ? s : -s}, v[3], nn[3];
     mulMatVec3(v, RTB, loc);
     for (int j = 0; j < 3; j++) v[j] += d[j];
     int ok;
     double dist = point_cyl(v, r, hl, nn, &ok);
-    if (ok && dist < best) {
-      best = dist; found = 1;
-      for (int j = 0; j < 3; j++) { bn[j] = nn[j]; bp[j] = v[j] - nn[j] * dist * 0.5; }
-    }
+    if (v[1] * v[1] + v[2] * v[2] < 1e-18) ok = 0;
+    if (ok && dist < best) { best = dist; found = 1; memcpy(wp, v, sizeof wp); }
   }
   for (int j = 0; j < 3; j++) {
     int j1 = (j + 1) % 3, j2 = (j + 2) % 3;
@@ -684,23 +682,23 @@ int bo_box_cyl_point(const double* d, const double* RTB, double s, double r, dou
     double dd = dir[1] * dir[1] + dir[2] * dir[2];
     if (dd < 1e-8) continue;
     for (int e = 0; e < 4; e++) {
-      double loc[3], o[3];
+      double loc[3], o[3], nn[3];
       loc[j] = 0; loc[j1] = (e & 1) ? s : -s; loc[j2] = (e & 2) ? s : -s;
       mulMatVec3(o, RTB, loc);
       for (int c = 0; c < 3; c++) o[c] += d[c];
       double tau = -(o[1] * dir[1] + o[2] * dir[2]) / dd;
       if (!(fabs(tau) < s)) continue;
       double p[3] = {o[0] + tau * dir[0], o[1] + tau * dir[1], o[2] + tau * dir[2]};
-      if (fabs(p[0]) > hl) continue;
-      double rho = sqrt(p[1] * p[1] + p[2] * p[2]);
-      if (rho < 1e-9) continue;
-      double dist = rho - r;
-      if (dist < best) {
-        best = dist; found = 1;
-        bn[0] = 0; bn[1] = p[1] / rho; bn[2] = p[2] / rho;
-        for (int c = 0; c < 3; c++) bp[c] = p[c] - bn[c] * dist * 0.5;
-      }
+      int ok;
+      double dist = point_cyl(p, r, hl, nn, &ok);
+      if (p[1] * p[1] + p[2] * p[2] < 1e-18) ok = 0;
+      if (ok && dist < best) { best = dist; found = 1; memcpy(wp, p, sizeof wp); }
     }
+  }
+  if (found) {
+    int ok;
+    point_cyl(wp, r, hl, bn, &ok);
+    for (int c = 0; c < 3; c++) bp[c] = wp[c] - bn[c] * best * 0.5;
   }
   double rho = sqrt(d[1] * d[1] + d[2] * d[2]);
   if (rho > 1e-9) {
@@ -713,12 +711,13 @@ int bo_box_cyl_point(const double* d, const double* RTB, double s, double r, dou
       mulMatTVec3(p, RTB, rel);
       double dist = point_box(p, ss, nb);
       if (dist < best) {
-        best = dist; found = 1;
+        best = dist; found = 1; from_c = 1;
         mulMatVec3(nw, RTB, nb);
         for (int c = 0; c < 3; c++) { bn[c] = -nw[c]; bp[c] = q[c] + bn[c] * dist * 0.5; }
       }
     }
   }
+  (void)from_c;
   if (!found) return 0;
   for (int c = 0; c < 3; c++) { pos[c] = bp[c]; nrm[c] = bn[c]; }
   *dist_out = best;

@@ -248,9 +248,7 @@ def test_errors_are_loud():
     s.close()
 
 
-@pytest.mark.parametrize("devices", [[0], pytest.param([0, 0], marks=pytest.mark.xfail(
-    reason="two handles on one GPU with their own streams: written after the round's GPU budget was spent, first run pending",
-    strict=False))])
+@pytest.mark.parametrize("devices", [[0], [0, 0]])
 def test_vec_env_on_the_gpu(devices):
     """BalanceVecEnv over real handles: one shard, and two shards of the SAME GPU on their own streams (overlapping
     kernels); both must give the env-index-keyed results of a single handle"""
@@ -269,7 +267,12 @@ def test_vec_env_on_the_gpu(devices):
         ro, rr, rte, rtr, rto = [x.cpu().numpy() for x in ref.step(torch.from_numpy(a).cuda())]
         np.testing.assert_array_equal(obs, ro); np.testing.assert_array_equal(rew, rr)
         np.testing.assert_array_equal(dones, (rte | rtr).astype(bool))
+        # eager arrays of the finished episodes, then the SB3-style dicts built from them on first access
+        np.testing.assert_array_equal(infos.done_indices, np.flatnonzero(dones))
+        np.testing.assert_array_equal(infos.terminal_observations, rto[dones])
         for i in np.flatnonzero(dones):
             np.testing.assert_array_equal(infos[i]["terminal_observation"], rto[i]); ndone += 1
+            assert infos[i]["TimeLimit.truncated"] == bool(rtr[i] and not rte[i]) and infos[i]["episode"]["l"] >= 1
+        assert infos[int(np.flatnonzero(~dones)[0])] == {}
     assert ndone > 0
     env.close(); ref.close()

@@ -87,6 +87,8 @@ def main():
     rng = np.random.default_rng(1234)
     outl, nsteps, over, excl, worst = [], 0, 0, 0, 0.0
     upright_over, upright_n = 0, 0
+    # per coordinate group x {upright, fallen}: max error and number of env-steps above tol
+    gstat = {f"{g}/{u}": [0.0, 0] for g in ("robot", "block") for u in ("upright", "fallen")}
     hist = np.zeros(12, dtype=np.int64)  # log10 buckets of the per-env-step error: <1e-10 ... >=1e0
     t0 = time.time()
     for t in range(a.steps):
@@ -110,6 +112,15 @@ def main():
         hist += np.bincount(np.clip(np.floor(np.log10(np.maximum(e[~skip], 1e-11))).astype(int) + 11, 0, 11), minlength=12)
         upright = 1 - 2 * (qpos[:, 4] ** 2 + qpos[:, 5] ** 2) > 0.5
         upright_n += int((upright & ~skip).sum()); upright_over += int((e[upright] > a.tol).sum())
+        dqa = np.where(skip[:, None], 0.0, np.abs(qs - qt))
+        for g, sl in (("robot", slice(0, 9)), ("block", slice(9, 16))):
+            if dqa.shape[1] <= sl.start:
+                continue
+            eg = dqa[:, sl].max(axis=1)
+            for u, m in (("upright", upright), ("fallen", ~upright)):
+                if m.any():
+                    gstat[f"{g}/{u}"][0] = max(gstat[f"{g}/{u}"][0], float(eg[m].max()))
+                    gstat[f"{g}/{u}"][1] += int((eg[m] > a.tol).sum())
         bad = np.nonzero(e > a.tol)[0]
         over += bad.size
         for i in bad:
@@ -126,6 +137,7 @@ def main():
             print(f"step {t}: worst {worst:.3g}, over {over}/{nsteps} ({time.time() - t0:.0f} s)", flush=True)
     rep = dict(env=a.env, envs=n, steps=a.steps, teacher=a.teacher, student=a.student, auto_reset=ar, tol=a.tol, actions=a.actions,
                env_steps=nsteps, excluded=excl, over=over, worst=worst, upright_env_steps=upright_n, upright_over=upright_over,
+               per_group={k: dict(max=v[0], over_tol=v[1]) for k, v in gstat.items()},
                log10_error_histogram={f"1e{k - 11}": int(v) for k, v in enumerate(hist)}, outliers=outl)
     json.dump(rep, open(a.out, "w"), indent=1)
     print(json.dumps({k: v for k, v in rep.items() if k != "outliers"}, indent=1))
