@@ -7,6 +7,8 @@ include/brs.h (libbrs_hip.so).  This package is the host-side mirror of the refe
     registry.make_vec(id, num_envs, ...)   ~ gym.make(id)  (src/balance_robot/__init__.py:5-52 of the reference)
     BalanceVecEnv                          ~ the SB3 VecEnv that sb_rl.py's PPO consumes (sb_rl.py:63-71, 552)
     BatchedSim                             zero-copy torch-tensor interface to the kernels
+    policy.DevicePolicy / DeviceRollout    SB3 MlpPolicy forward + sampling, time-limit bootstrap and GAE as HIP kernels
+                                           (include/brs_policy.h): the rollout side of sb_rl.py:63-71, 552-556 on the GPU
 
 There is no CPU fallback: creating a sim without a HIP device raises.
 """

@@ -6,13 +6,18 @@ import subprocess
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libbrs_hip.so")
 SRC = os.path.join(_PKG, "csrc", "brs_kernels.hip")
+SRC_POLICY = os.path.join(_PKG, "csrc", "brs_policy.hip")
 HEADERS = [os.path.join(_PKG, "csrc", h) for h in ("brs_core.hpp", "brs_model.hpp", "brs_state.hpp")] + \
-          [os.path.join(os.path.dirname(_PKG), "include", "brs.h")]
+          [os.path.join(os.path.dirname(_PKG), "include", h) for h in ("brs.h", "brs_policy.h")]
 
 # every symbol include/brs.h declares
 SYMBOLS = ["brs_create", "brs_destroy", "brs_last_error", "brs_sizes", "brs_reset", "brs_step", "brs_physics",
            "brs_get_state", "brs_set_state", "brs_get_aux", "brs_set_aux", "brs_get_xpose", "brs_set_xpose",
-           "brs_step_bytes_per_env", "brs_step_kernel_name"]
+           "brs_step_bytes_per_env", "brs_step_kernel_name",
+           # include/brs_policy.h
+           "brs_policy_create", "brs_policy_destroy", "brs_policy_last_error", "brs_policy_set_weights",
+           "brs_policy_use_device_weights", "brs_policy_act", "brs_policy_value", "brs_rollout_bootstrap", "brs_gae"]
+POLICY_NPARAM = (64 * 6 + 64 + 64 * 64 + 64 + 2 * 64 + 2) + (64 * 6 + 64 + 64 * 64 + 64 + 64 + 1) + 2
 
 
 class BrsConfig(C.Structure):
@@ -33,21 +38,27 @@ def hipcc_path():
 
 def build(force=False, verbose=False):
     """compile the HIP kernels + C ABI for gfx950 in-tree (hipcc cross-compiles without a GPU)"""
-    srcs = [SRC] + HEADERS
+    srcs = [SRC, SRC_POLICY] + HEADERS
     stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if not (force or stale):
         return LIB_PATH
-    # -ffast-math on the DEVICE side only (the host-side state conversion keeps IEEE semantics): no IEEE division/sqrt expansions and free reassociation inside the fp32 force path
-    # (parity budget is 1e-4, rounding noise 1e-7); NaN detection in the kernel is done on the bit pattern.
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-Xarch_device", "-ffast-math",
-           "-Xarch_device", "-fgpu-flush-denormals-to-zero",
-           # the dense algebra is packed by hand (V2 -> v_pk_fma_f32); the SLP vectoriser's extra packing of the scalar
-           # code only adds pack/unpack moves (measured: +13 % env-steps/s without it)
-           "-Xarch_device", "-fno-slp-vectorize", "-fPIC", "-shared", "-o", LIB_PATH, SRC]
-    cmd += os.environ.get("BRS_EXTRA_HIPCC_FLAGS", "").split()  # ablation builds (e.g. -DBRS_NO_COUPLED); not for production
+    hipcc = hipcc_path()
+    base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+    # step kernels: -ffast-math on the DEVICE side only (the host-side state conversion keeps IEEE semantics): no IEEE
+    # division/sqrt expansions and free reassociation inside the fp32 force path (parity budget is 1e-4, rounding noise 1e-7);
+    # NaN detection in the kernel is done on the bit pattern.
+    sim_flags = ["-Xarch_device", "-ffast-math", "-Xarch_device", "-fgpu-flush-denormals-to-zero",
+                 # the dense algebra is packed by hand (V2 -> v_pk_fma_f32); the SLP vectoriser's extra packing of the scalar
+                 # code only adds pack/unpack moves (measured: +13 % env-steps/s without it)
+                 "-Xarch_device", "-fno-slp-vectorize"]
+    sim_flags += os.environ.get("BRS_EXTRA_HIPCC_FLAGS", "").split()  # ablation builds (e.g. -DBRS_NO_COUPLED); not for production
     if verbose:
-        cmd.append("-Rpass-analysis=kernel-resource-usage")
-    subprocess.check_call(cmd)
+        sim_flags.append("-Rpass-analysis=kernel-resource-usage")
+    obj_sim, obj_pol = os.path.join(_PKG, "csrc", "brs_kernels.o"), os.path.join(_PKG, "csrc", "brs_policy.o")
+    subprocess.check_call(base + sim_flags + ["-c", "-o", obj_sim, SRC])
+    # policy / GAE kernels: IEEE math (tanh, exp, log at libm accuracy): the parity test is rtol 1e-5 against fp32 torch
+    subprocess.check_call(base + ["-c", "-o", obj_pol, SRC_POLICY])
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, obj_sim, obj_pol])
     return LIB_PATH
 
 
@@ -82,5 +93,16 @@ def lib():
     L.brs_step_bytes_per_env.restype = C.c_int64
     L.brs_step_kernel_name.argtypes = [vp]
     L.brs_step_kernel_name.restype = C.c_char_p
+    i32, u64, i64, u32, f32 = C.c_int32, C.c_uint64, C.c_int64, C.c_uint32, C.c_float
+    L.brs_policy_create.argtypes = [i32, C.POINTER(vp)]
+    L.brs_policy_destroy.argtypes = [vp]
+    L.brs_policy_last_error.argtypes = [vp]
+    L.brs_policy_last_error.restype = C.c_char_p
+    L.brs_policy_set_weights.argtypes = [vp, C.POINTER(C.c_float)]
+    L.brs_policy_use_device_weights.argtypes = [vp, vp]
+    L.brs_policy_act.argtypes = [vp, i32, vp, u64, i64, u32, i32, vp, vp, vp, vp, vp, vp]
+    L.brs_policy_value.argtypes = [vp, i32, vp, vp, vp]
+    L.brs_rollout_bootstrap.argtypes = [vp, i32, vp, vp, vp, f32, vp, vp]
+    L.brs_gae.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp]
     _lib = L
     return L

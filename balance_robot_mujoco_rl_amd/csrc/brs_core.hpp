@@ -201,11 +201,14 @@ template <typename R> struct Stream {
 };
 
 // ------------------------------------------------------------------------------------ per-lane contact store
-// floor-contact slots hold 7 words, coupled slots 13; word k of the lane's column lives at base[k*stride]
-// (GPU: stride 64 = one LDS row per word, consecutive lanes on consecutive banks)
-enum { SLOT_ROBOT = 0, N_ROBOT_SLOTS = 8, SLOT_BLOCK = 8, N_BLOCK_SLOTS = 4, N_COUPLED_SLOTS = 4, SLOT_WORDS = 7,
-       COUPLED_WORDS = 13, COUPLED_BASE = (N_ROBOT_SLOTS + N_BLOCK_SLOTS) * SLOT_WORDS,
-       LDS_WORDS_ENV01 = N_ROBOT_SLOTS * SLOT_WORDS, LDS_WORDS_ENV03 = COUPLED_BASE + N_COUPLED_SLOTS * COUPLED_WORDS };
+// floor-contact slots hold 7 words, coupled (block<->robot) slots 10 plus 3 shared contact-frame slots of 3 words (frame 0:
+// the torso<->block patch, 1 / 2: the wheel contacts); word k of the lane's column lives at base[k*stride]
+// (GPU: stride 64 = one LDS row per word, consecutive lanes on consecutive banks).  6 coupled slots = 4 patch points + one
+// point per wheel: the generator can never produce more, nothing is dropped.  153 words/lane = 38.25 KiB per wave: 4 waves/CU.
+enum { SLOT_ROBOT = 0, N_ROBOT_SLOTS = 8, SLOT_BLOCK = 8, N_BLOCK_SLOTS = 4, N_COUPLED_SLOTS = 6, SLOT_WORDS = 7,
+       COUPLED_WORDS = 10, COUPLED_BASE = (N_ROBOT_SLOTS + N_BLOCK_SLOTS) * SLOT_WORDS,
+       FRAME_BASE = COUPLED_BASE + N_COUPLED_SLOTS * COUPLED_WORDS, N_FRAME_SLOTS = 3,
+       LDS_WORDS_ENV01 = N_ROBOT_SLOTS * SLOT_WORDS, LDS_WORDS_ENV03 = FRAME_BASE + 3 * N_FRAME_SLOTS };
 template <typename R> struct Store {
   R* base;
   int stride;
@@ -213,17 +216,18 @@ template <typename R> struct Store {
   BRS_HD void set(int s, int w, R v) { base[(s * SLOT_WORDS + w) * stride] = v; }
   BRS_HD R getc(int c, int w) const { return base[(COUPLED_BASE + c * COUPLED_WORDS + w) * stride]; }
   BRS_HD void setc(int c, int w, R v) { base[(COUPLED_BASE + c * COUPLED_WORDS + w) * stride] = v; }
+  BRS_HD R getf(int f, int w) const { return base[(FRAME_BASE + 3 * f + w) * stride]; }
+  BRS_HD void setf(int f, int w, R v) { base[(FRAME_BASE + 3 * f + w) * stride] = v; }
 };
 // Per-lane bookkeeping of the contact lists lives in registers, not in LDS: 4-bit active-row masks packed 8 slots
-// to a word (R: robot<->floor slots 0..7; X: block<->floor 0..3 and block<->robot 4..7), body selectors 2 bits per slot.
-struct Masks { uint32_t hR, hX, nR, nX; };  // h: the masks H was built with; n: masks at the latest evaluated point
+// to a word (R: robot<->floor slots 0..7; B: block<->floor 0..3; C: block<->robot 0..5), body selectors 2 bits per slot.
+struct Masks { uint32_t hR, hB, hC, nR, nB, nC; };  // h: the masks H was built with; n: masks at the latest evaluated point
 BRS_HD int get4(uint32_t m, int slot) { return (int)((m >> (4 * slot)) & 15u); }
 BRS_HD uint32_t put4(int v, int slot) { return (uint32_t)v << (4 * slot); }
-// sels word: bits [0,16) robot<->floor body (0 torso, 1 L wheel, 2 R wheel), [16,24) block<->robot body, [24,28) "same
-// contact frame as the previous coupled slot"
+// sels word: bits [0,16) robot<->floor body (0 torso, 1 L wheel, 2 R wheel), [16,28) block<->robot body (which is also the
+// contact-frame slot: the torso patch shares frame 0, each wheel contact owns frame 1 / 2)
 BRS_HD int sel_robot(uint32_t sels, int c) { return (int)((sels >> (2 * c)) & 3u); }
 BRS_HD int sel_coupled(uint32_t sels, int c) { return (int)((sels >> (16 + 2 * c)) & 3u); }
-BRS_HD bool share_coupled(uint32_t sels, int c) { return ((sels >> (24 + c)) & 1u) != 0; }
 
 // ------------------------------------------------------------------------------------ env state (registers)
 template <typename R, bool BLK> struct EnvState {
@@ -247,7 +251,7 @@ template <typename R, bool BLK> struct EnvState {
   R muw;            // Env02: wheel/floor friction of this episode (envs/env02_v1.py:57-65)
   R dts, poff, tws; // Env01-v3: delay_target_speed, pitch_offset, target_wheel_speed (envs/env01_v3.py:16-53)
   int pnfr, pnfb, pnc;  // previous substep: contact-list lengths, body selectors and final active-row masks -- the first
-  uint32_t psels, pmR, pmX;  // guess of this substep's active set (not persisted across launches)
+  uint32_t psels, pmR, pmB, pmC;  // guess of this substep's active set (not persisted across launches)
 };
 
 template <typename R> BRS_HD R impedance_(const ContactClass<R>& c, R dist) {
@@ -428,7 +432,7 @@ template <typename R, bool BLK> struct Sim {
     R a0[NV];          // unconstrained acceleration (body coords)
     int nfr, nfb, nc;  // robot-floor, block-floor, coupled contact counts of this lane
     int pnfr, pnfb, pnc;  // the same of the previous substep
-    uint32_t sels, psels, pmR, pmX;
+    uint32_t sels, psels, pmR, pmB, pmC;
     R muW, cDW;        // wheel<->floor friction and pyramid regulariser factor of this env
   };
 
@@ -586,7 +590,8 @@ template <typename R, bool BLK> struct Sim {
     fw[3] *= il; fw[4] *= il; fw[5] *= il;
     cross_(fw, fw + 3, fw + 6);
   }
-  // coupled record (13 words): rT(3) torso frame, rB(3) block frame, nW(3) world normal robot->block, An, Bt1, Bt2, D.
+  // coupled record (10 words): rT(3) torso frame, rB(3) block frame, An, Bt1, Bt2, D; the world normal robot->block of its
+  // patch goes to contact-frame slot `sel` (written by the patch's first point, share = false).
   // fw = world contact frame (normal + MuJoCo's mju_makeFrame tangents), built once per patch by the caller.
   static BRS_HD void add_coupled(const Params<R>& P, Store<R>& st, Frame& F, const ES& S, const R* rT, const R* fw, R dist,
                                  int sel, bool share) {
@@ -612,12 +617,12 @@ template <typename R, bool BLK> struct Sim {
     int k = F.nc;
     st.setc(k, 0, rT[0]); st.setc(k, 1, rT[1]); st.setc(k, 2, rT[2]);
     st.setc(k, 3, rB[0]); st.setc(k, 4, rB[1]); st.setc(k, 5, rB[2]);
-    st.setc(k, 6, fw[0]); st.setc(k, 7, fw[1]); st.setc(k, 8, fw[2]);
-    st.setc(k, 9, -c.B * vn - c.K * imp * (dist - c.margin));
-    st.setc(k, 10, -c.B * c.mu * vt1);
-    st.setc(k, 11, -c.B * c.mu * vt2);
-    st.setc(k, 12, imp * rcp_((1 - imp) * cD));
-    F.sels |= ((uint32_t)sel << (16 + 2 * k)) | ((share && k > 0) ? (1u << (24 + k)) : 0u);
+    st.setc(k, 6, -c.B * vn - c.K * imp * (dist - c.margin));
+    st.setc(k, 7, -c.B * c.mu * vt1);
+    st.setc(k, 8, -c.B * c.mu * vt2);
+    st.setc(k, 9, imp * rcp_((1 - imp) * cD));
+    if (!share) { st.setf(sel, 0, fw[0]); st.setf(sel, 1, fw[1]); st.setf(sel, 2, fw[2]); }
+    F.sels |= (uint32_t)sel << (16 + 2 * k);
     F.nc++;
   }
   static BRS_HD void world_frame(const Frame& F, const R* nTf, R* fw) {  // unit normal in the torso frame -> world contact frame
@@ -1016,15 +1021,17 @@ template <typename R, bool BLK> struct Sim {
     R An, Bt1, Bt2, D, mu;
     int sel;
   };
-  // C persists across the contacts of one pass: a contact flagged "share" in F.sels reuses the frame rows of its predecessor
+  // C persists across the contacts of one pass: a contact of the same patch (same body selector as its predecessor) reuses
+  // the frame rows already rotated into both body frames
   static BRS_HD void coupled_load(const Params<R>& P, const Store<R>& st, const Frame& F, int c, Coupled& C) {
 #pragma unroll
     for (int j = 0; j < 3; j++) { C.rT[j] = st.getc(c, j); C.rB[j] = st.getc(c, 3 + j); }
-    C.An = st.getc(c, 9); C.Bt1 = st.getc(c, 10); C.Bt2 = st.getc(c, 11); C.D = st.getc(c, 12);
+    C.An = st.getc(c, 6); C.Bt1 = st.getc(c, 7); C.Bt2 = st.getc(c, 8); C.D = st.getc(c, 9);
+    const int prev_sel = C.sel;
     C.sel = sel_coupled(F.sels, c);
     C.mu = P.cc[CC_BLOCK_ROBOT].mu;
-    if (!share_coupled(F.sels, c)) {
-      R fw[9] = {st.getc(c, 6), st.getc(c, 7), st.getc(c, 8), 0, 0, 0, 0, 0, 0};
+    if (c == 0 || C.sel != prev_sel) {  // a new patch: its frame (the torso patch is contiguous, a wheel contact is alone)
+      R fw[9] = {st.getf(C.sel, 0), st.getf(C.sel, 1), st.getf(C.sel, 2), 0, 0, 0, 0, 0, 0};
       make_frame(fw);
 #pragma unroll
       for (int k = 0; k < 3; k++) { mulT_(F.RT, fw + 3 * k, C.dT[k]); mulT_(F.RB, fw + 3 * k, C.dB[k]); }
@@ -1079,7 +1086,7 @@ template <typename R, bool BLK> struct Sim {
     static BRS_HD void passA(const Params<R>& P, Store<R>& st, const Frame& F, Masks& M, const R* x, const R* a0, R& cost,
                              R* fcon, bool& same) {
       R Md[NN], cst = 0, l[4];
-      M.nR = 0; M.nX = 0;
+      M.nR = 0; M.nB = 0; M.nC = 0;
       if constexpr (FORCES) gauss(P, x, a0, Md, cst);  // the cost only steers the damped fallback
 #pragma unroll
       for (int i = 0; i < NN; i++) fcon[i] = 0;
@@ -1119,8 +1126,8 @@ template <typename R, bool BLK> struct Sim {
           R t[3];
           cross_(x + 11, r, t);
           R pa[3] = {x[8] + t[0], x[9] + t[1], x[10] + t[2]};
-          int mk = rows_(dot_(F.nB(), pa) - An, mu * dot_(F.t1B(), pa) - Bt1, -mu * dot_(F.xB(), pa) - Bt2, D, cst, l, get4(M.hX, c), sm);
-          M.nX |= put4(mk, c);
+          int mk = rows_(dot_(F.nB(), pa) - An, mu * dot_(F.t1B(), pa) - Bt1, -mu * dot_(F.xB(), pa) - Bt2, D, cst, l, get4(M.hB, c), sm);
+          M.nB |= put4(mk, c);
           if constexpr (FORCES) {
             R fn = D * (l[0] + l[1] + l[2] + l[3]), f1 = D * mu * (l[0] - l[1]), f2 = D * mu * (l[2] - l[3]);
             R fb[3] = {F.nB()[0] * fn + F.t1B()[0] * f1 - F.xB()[0] * f2, F.nB()[1] * fn + F.t1B()[1] * f1 - F.xB()[1] * f2,
@@ -1131,6 +1138,7 @@ template <typename R, bool BLK> struct Sim {
           }
         }
         Coupled C;
+        C.sel = -1;
         for (int c = 0; c < F.nc; c++) {
           coupled_load(P, st, F, c, C);
           R t[3];
@@ -1141,8 +1149,8 @@ template <typename R, bool BLK> struct Sim {
           cross_(x + 11, C.rB, t);
           R paB[3] = {x[8] + t[0], x[9] + t[1], x[10] + t[2]};
           int mk = rows_(dot_(C.dB[0], paB) - dot_(C.dT[0], paT) - C.An, C.mu * (dot_(C.dB[1], paB) - dot_(C.dT[1], paT)) - C.Bt1,
-                         C.mu * (dot_(C.dB[2], paB) - dot_(C.dT[2], paT)) - C.Bt2, C.D, cst, l, get4(M.hX, 4 + c), sm);
-          M.nX |= put4(mk, 4 + c);
+                         C.mu * (dot_(C.dB[2], paB) - dot_(C.dT[2], paT)) - C.Bt2, C.D, cst, l, get4(M.hC, c), sm);
+          M.nC |= put4(mk, c);
           if constexpr (FORCES) {
             R fn = C.D * (l[0] + l[1] + l[2] + l[3]), f1 = C.D * C.mu * (l[0] - l[1]), f2 = C.D * C.mu * (l[2] - l[3]);
             R fT[3], fB[3];
@@ -1215,8 +1223,8 @@ template <typename R, bool BLK> struct Sim {
                                 V2<R>* H, V2<R>* rhs2) {
       // active rows of this piece: the latest evaluated masks; on the first iteration the previous substep's final
       // masks where the slot held a contact of the same body then (else the rows are evaluated at x)
-      const uint32_t srcR = first ? F.pmR : M.nR, srcX = first ? F.pmX : M.nX;
-      M.hR = 0; M.hX = 0;
+      const uint32_t srcR = first ? F.pmR : M.nR, srcB = first ? F.pmB : M.nB, srcC = first ? F.pmC : M.nC;
+      M.hR = 0; M.hB = 0; M.hC = 0;
 #pragma unroll
       for (int i = 0; i < NH2; i++) H[i] = v2_splat<R>((R)0);
       h2_set(H, 0, 0, P.m); h2_set(H, 1, 1, P.m); h2_set(H, 2, 2, P.m);
@@ -1264,10 +1272,11 @@ template <typename R, bool BLK> struct Sim {
           V2<R> gn[3] = {v2_make(F.nB()[0], F.nB()[1]), v2_make(F.nB()[2], rn[0]), v2_make(rn[1], rn[2])};
           V2<R> g1[3] = {v2_make(F.t1B()[0], F.t1B()[1]), v2_make(F.t1B()[2], r1[0]), v2_make(r1[1], r1[2])};
           V2<R> g2[3] = {v2_make(-F.xB()[0], -F.xB()[1]), v2_make(-F.xB()[2], r2[0]), v2_make(r2[1], r2[2])};
-          int mk = contact_into<4, 3>(H, rhs2, gn, g1, g2, P.cc[CC_BLOCK_FLOOR].mu, D, An, Bt1, Bt2, ev, get4(srcX, c), x2);
-          M.hX |= put4(mk, c);
+          int mk = contact_into<4, 3>(H, rhs2, gn, g1, g2, P.cc[CC_BLOCK_FLOOR].mu, D, An, Bt1, Bt2, ev, get4(srcB, c), x2);
+          M.hB |= put4(mk, c);
         }
         Coupled C;
+        C.sel = -1;
         for (int c = 0; c < F.nc; c++) {
           coupled_load(P, st, F, c, C);
           V2<R> g[3][7];
@@ -1282,8 +1291,8 @@ template <typename R, bool BLK> struct Sim {
             g[k][4] = v2_make(C.dB[k][0], C.dB[k][1]); g[k][5] = v2_make(C.dB[k][2], cb[0]); g[k][6] = v2_make(cb[1], cb[2]);
           }
           const bool ev = first && !(BRS_MASK_HINT && c < F.pnc && sel_coupled(F.psels, c) == C.sel);
-          int mk = contact_into<0, 7>(H, rhs2, g[0], g[1], g[2], C.mu, C.D, C.An, C.Bt1, C.Bt2, ev, get4(srcX, 4 + c), x2);
-          M.hX |= put4(mk, 4 + c);
+          int mk = contact_into<0, 7>(H, rhs2, g[0], g[1], g[2], C.mu, C.D, C.An, C.Bt1, C.Bt2, ev, get4(srcC, c), x2);
+          M.hC |= put4(mk, c);
         }
       }
     }
@@ -1388,7 +1397,7 @@ template <typename R, bool BLK> struct Sim {
     BRS_TOC(0);
     F.nfr = 0; F.nfb = 0; F.nc = 0;
     F.pnfr = S.pnfr; F.pnfb = S.pnfb; F.pnc = S.pnc;
-    F.sels = 0; F.psels = S.psels; F.pmR = S.pmR; F.pmX = S.pmX;
+    F.sels = 0; F.psels = S.psels; F.pmR = S.pmR; F.pmB = S.pmB; F.pmC = S.pmC;
     F.muW = P.per_env_mu ? S.muw : P.cc[CC_WHEEL_FLOOR].mu;
     F.cDW = P.per_env_mu ? 2 * S.muw * S.muw * (1 + S.muw * S.muw) * P.tran_wheel : P.cc[CC_WHEEL_FLOOR].cD;
     R uB[3] = {0, 0, 0}, zB = 0;
@@ -1430,7 +1439,7 @@ template <typename R, bool BLK> struct Sim {
     }
     BRS_MARK("begin_tail");
     C.first = true; C.it = 0; C.cost = 0;
-    C.M.hR = 0; C.M.hX = 0; C.M.nR = 0; C.M.nX = 0;
+    C.M.hR = 0; C.M.hB = 0; C.M.hC = 0; C.M.nR = 0; C.M.nB = 0; C.M.nC = 0;
     C.conv = F.nfr + F.nfb + F.nc == 0;
     if (C.conv) {  // no contacts: the unconstrained acceleration is the answer
 #pragma unroll
@@ -1479,7 +1488,7 @@ template <typename R, bool BLK> struct Sim {
     }
     S.time += P.h_d;
     // first guess of the next substep's active set
-    S.pnfr = F.nfr; S.pnfb = F.nfb; S.pnc = F.nc; S.psels = F.sels; S.pmR = C.M.nR; S.pmX = C.M.nX;
+    S.pnfr = F.nfr; S.pnfb = F.nfb; S.pnc = F.nc; S.psels = F.sels; S.pmR = C.M.nR; S.pmB = C.M.nB; S.pmC = C.M.nC;
     for (int i_ = 0; i_ < 3; i_++) { BRS_PIN(S.v[i_]); BRS_PIN(S.w[i_]); BRS_PIN(S.p[i_]); }
     for (int i_ = 0; i_ < 4; i_++) BRS_PIN(S.q[i_]);
     BRS_PIN(S.ww[0]); BRS_PIN(S.ww[1]);

@@ -23,7 +23,7 @@
 #if defined(BRS_TIMING)
 __device__ unsigned long long brs_dbg[16];
 __device__ unsigned long long brs_dbg_wave[4096];
-#define BRS_TIMING_LANE_WORDS 136
+#define BRS_TIMING_LANE_WORDS 153
 #endif
 #include "brs_state.hpp"
 

@@ -57,7 +57,7 @@ BRS_HD void load_state_phys(EnvState<R, BLK>& S, const double* d, const FT* f, c
   S.rng_ctr = (uint32_t)ii[L::I_RNG * N + i];
   S.side_front = ii[L::I_SIDE * N + i];
   S.muw = (R)f[L::F_MUW * N + i];
-  S.pnfr = 0; S.pnfb = 0; S.pnc = 0; S.psels = 0; S.pmR = 0; S.pmX = 0;
+  S.pnfr = 0; S.pnfb = 0; S.pnc = 0; S.psels = 0; S.pmR = 0; S.pmB = 0; S.pmC = 0;
 }
 // ... and the env-level scalars, only needed before and after the loop
 template <typename R, bool BLK, typename FT>

@@ -1,4 +1,4 @@
-"""The C-ABI library loads without a GPU and exports every symbol include/brs.h declares; without a device it fails
+"""The C-ABI library loads without a GPU and exports every symbol include/*.h declares; without a device it fails
 loudly (there is no CPU fallback in the product)."""
 import ctypes as C
 import os
@@ -10,9 +10,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _declared():
-    txt = open(os.path.join(ROOT, "include", "brs.h")).read()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(brs_[a-z_0-9]+)\s*\(", txt)))
+    names = set()
+    for h in ("brs.h", "brs_policy.h"):
+        txt = open(os.path.join(ROOT, "include", h)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        names |= set(re.findall(r"\b(brs_[a-z_0-9]+)\s*\(", txt))
+    return sorted(names)
 
 
 def test_header_symbols_exported():
@@ -22,7 +25,7 @@ def test_header_symbols_exported():
     names = _declared()
     assert len(names) >= 15
     for n in names:
-        assert hasattr(L, n), f"{n} declared in include/brs.h but not exported by libbrs_hip.so"
+        assert hasattr(L, n), f"{n} declared in include/*.h but not exported by libbrs_hip.so"
     assert sorted(_lib.SYMBOLS) == names
 
 
@@ -42,6 +45,9 @@ def test_sizes_and_bad_args_without_device():
     assert L.brs_create(C.byref(cfg), C.byref(h)) == -1
     cfg = _lib.BrsConfig(1, 8, 0, 6, 0, 0, 0, 0, 0.0, 0, 0)  # NOISE_ON | NOISE_OFF
     assert L.brs_create(C.byref(cfg), C.byref(h)) == -1
+    # include/brs_policy.h: argument checks that need no device
+    assert L.brs_policy_create(0, None) == -1
+    assert L.brs_gae(0, 0, 4, None, None, None, None, None, 0.99, 0.95, None, None, None) == -1
 
 
 def test_no_cpu_fallback():

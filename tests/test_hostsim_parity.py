@@ -89,19 +89,18 @@ def test_constructed_block_robot_contact_states(double, tol):
     o = O.Oracle("Env03-v2", n, noise=False, threads=8)
     h = HostSim("Env03-v2", n, noise=False, double=double)
     o.set_state(qpos, qvel); h.set_state(qpos, qvel)
-    # capacity limit of the kernel (out of scope): 4 block<->robot slots per env.  A 4-point torso patch plus a
-    # wheel point is 5 -- the oracle keeps all, the kernel drops the wheel point.  Leave those states out (and count them).
-    fits = np.ones(n, bool)
+    # the kernel holds 6 block<->robot slots (4 patch points + one per wheel): whatever the generator emits fits
     ctrl = np.zeros((n, 2))
+    most = 0
     for _ in range(5):
-        fits &= np.array([sum(1 for c in o.forward(env=i)["contacts"] if c["body2"] == 4 and c["body1"] != 0) for i in range(n)]) <= 4
+        most = max(most, max(sum(1 for c in o.forward(env=i)["contacts"] if c["body2"] == 4 and c["body1"] != 0) for i in range(n)))
         o.physics(ctrl, 1); h.physics(ctrl, 1)
-    assert fits.mean() > 0.95, fits.mean()
+    assert 5 <= most <= 6, most   # the states must exercise more than the 4 slots of round 1
     (qo, vo, _, _), (qh, vh, _, _) = o.get_state(), h.get_state()
     touched = np.abs(vo[:, :6]).max(axis=1) > 1e-6          # the robot was pushed: a coupled contact acted
     assert touched.sum() > n // 3
     scale = 1.0 + np.abs(vo).max(axis=1)
-    err = (np.abs(vo - vh).max(axis=1) / scale)[fits]
+    err = np.abs(vo - vh).max(axis=1) / scale
     assert np.quantile(err, 0.98) < tol and err.max() < 50 * tol, (np.quantile(err, 0.98), err.max())
 
 

@@ -1,0 +1,165 @@
+"""On-device rollout kernels (include/brs_policy.h) against plain fp32 PyTorch / numpy references
+of what SB3 does on the host: ActorCriticPolicy.forward (6-64-64 tanh towers, action_net / value_net, diagonal Gaussian),
+the time-limit bootstrap of collect_rollouts and RolloutBuffer.compute_returns_and_advantage [3P stable_baselines3; the
+reference configures it at src/sb_rl.py:63-71 and runs it at src/sb_rl.py:552-556].  Tolerance: rtol 1e-5."""
+import math
+
+import numpy as np
+import pytest
+
+
+def _ref_gae(rew, val, start, last_val, last_done, gamma, lam):
+    """SB3 RolloutBuffer.compute_returns_and_advantage, float32 like SB3's buffers"""
+    T, N = rew.shape
+    adv = np.zeros((T, N), np.float32)
+    last = np.zeros(N, np.float32)
+    for t in reversed(range(T)):
+        if t == T - 1:
+            nnt, nv = 1.0 - last_done.astype(np.float32), last_val
+        else:
+            nnt, nv = 1.0 - start[t + 1].astype(np.float32), val[t + 1]
+        delta = rew[t] + np.float32(gamma) * nv * nnt - val[t]
+        last = delta + np.float32(gamma) * np.float32(lam) * nnt * last
+        adv[t] = last
+    return adv, adv + val
+
+
+def test_library_exports_the_policy_symbols_and_layout():
+    from balance_robot_mujoco_rl_amd import _lib
+    L = _lib.lib()
+    for s in ("brs_policy_create", "brs_policy_act", "brs_policy_value", "brs_rollout_bootstrap", "brs_gae"):
+        assert hasattr(L, s)
+    assert _lib.POLICY_NPARAM == 4738 + 4673 + 2
+    hdr = open(__import__("os").path.join(__import__("os").path.dirname(__file__), "..", "include", "brs_policy.h")).read()
+    for s in _lib.SYMBOLS:
+        if s.startswith("brs_policy") or s in ("brs_gae", "brs_rollout_bootstrap"):
+            assert s + "(" in hdr
+
+
+def test_reference_gae_recursion_on_a_hand_case():
+    """the numpy reference itself against numbers worked by hand (gamma = 0.5, lambda = 1): two envs, three steps"""
+    rew = np.array([[1, 1], [1, 1], [1, 1]], np.float32); val = np.zeros((3, 2), np.float32)
+    start = np.array([[1, 1], [0, 0], [0, 1]], np.uint8)   # env 1 starts a new episode at t = 2
+    adv, ret = _ref_gae(rew, val, start, np.array([4, 4], np.float32), np.array([0, 1], np.uint8), 0.5, 1.0)
+    np.testing.assert_allclose(adv[:, 0], [1 + 0.5 * (1 + 0.5 * (1 + 0.5 * 4)), 1 + 0.5 * (1 + 0.5 * 4), 1 + 0.5 * 4])
+    np.testing.assert_allclose(adv[:, 1], [1 + 0.5 * 1, 1, 1])
+
+
+@pytest.mark.gpu
+def test_policy_forward_sample_and_logprob_match_torch_fp32():
+    import torch
+    from balance_robot_mujoco_rl_amd.policy import DevicePolicy, SB3_LAYOUT, flatten_sb3_state_dict
+    torch.manual_seed(0)
+    pi = torch.nn.Sequential(torch.nn.Linear(6, 64), torch.nn.Tanh(), torch.nn.Linear(64, 64), torch.nn.Tanh())
+    vf = torch.nn.Sequential(torch.nn.Linear(6, 64), torch.nn.Tanh(), torch.nn.Linear(64, 64), torch.nn.Tanh())
+    an, vn = torch.nn.Linear(64, 2), torch.nn.Linear(64, 1)
+    log_std = torch.tensor([-0.3, 0.2])
+    sd = {"mlp_extractor.policy_net.0.weight": pi[0].weight, "mlp_extractor.policy_net.0.bias": pi[0].bias,
+          "mlp_extractor.policy_net.2.weight": pi[2].weight, "mlp_extractor.policy_net.2.bias": pi[2].bias,
+          "action_net.weight": an.weight, "action_net.bias": an.bias,
+          "mlp_extractor.value_net.0.weight": vf[0].weight, "mlp_extractor.value_net.0.bias": vf[0].bias,
+          "mlp_extractor.value_net.2.weight": vf[2].weight, "mlp_extractor.value_net.2.bias": vf[2].bias,
+          "value_net.weight": vn.weight, "value_net.bias": vn.bias, "log_std": log_std}
+    assert [k for k, _ in SB3_LAYOUT] == list(sd.keys())
+    n = 4096 + 37   # a partial last wave
+    obs = (torch.randn(n, 6) * torch.tensor([1.5, 4.0, 0.5, 0.5, 0.5, 0.5])).float()
+    pol = DevicePolicy(device=0, seed=5, env_index_base=1000)
+    pol.set_weights(sd)
+    noise = torch.empty((n, 2), dtype=torch.float32, device="cuda")
+    a, ac, lp, v = pol.act(obs.cuda(), step=3, noise=noise)
+    torch.cuda.synchronize()
+    with torch.no_grad():   # the reference: plain fp32 torch on the CPU, fed the SAME standard normals
+        mean, val = an(pi(obs)), vn(vf(obs)).squeeze(1)
+        z = noise.cpu()
+        a_ref = mean + log_std.exp() * z
+        dist = torch.distributions.Normal(mean, log_std.exp().expand_as(mean))
+        lp_ref = dist.log_prob(a_ref).sum(1)
+    np.testing.assert_allclose(a.cpu().numpy(), a_ref.numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(ac.cpu().numpy(), a_ref.clamp(-1, 1).numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(v.cpu().numpy(), val.numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(lp.cpu().numpy(), lp_ref.numpy(), rtol=1e-5, atol=1e-5)
+    # the noise: standard normal, one Philox block per (env, step) -- reproducible, different per step and per env
+    zz = z.numpy()
+    assert abs(zz.mean()) < 0.05 and abs(zz.std() - 1) < 0.05 and abs(np.corrcoef(zz[:, 0], zz[:, 1])[0, 1]) < 0.05
+    noise2 = torch.empty_like(noise); pol.act(obs.cuda(), step=3, noise=noise2)
+    noise3 = torch.empty_like(noise); pol.act(obs.cuda(), step=4, noise=noise3)
+    torch.cuda.synchronize()
+    assert torch.equal(noise, noise2) and not torch.equal(noise, noise3)
+    # keyed by GLOBAL env index: a shard starting at index 1000 + 64 reproduces rows 64.. of the full batch
+    pol2 = DevicePolicy(device=0, seed=5, env_index_base=1064); pol2.set_weights(sd)
+    nz = torch.empty((n - 64, 2), dtype=torch.float32, device="cuda"); pol2.act(obs[64:].cuda(), step=3, noise=nz)
+    torch.cuda.synchronize()
+    assert torch.equal(nz, noise[64:])
+    # Philox known answer: same generator as the simulator / oracle (counter = (step, "POLI", gid_lo, gid_hi), key = seed)
+    from oracle import oracle as O
+    o = O.philox([3, 0x504f4c49, 1000, 0], [5, 0])
+    u1, u2 = ((o[0] >> 8) + 0.5) / 16777216.0, ((o[1] >> 8) + 0.5) / 16777216.0
+    r = math.sqrt(-2 * math.log(u1))
+    np.testing.assert_allclose(zz[0], [r * math.cos(2 * math.pi * u2), r * math.sin(2 * math.pi * u2)], rtol=2e-5, atol=2e-6)
+    # deterministic mode = the mean; value head on its own
+    a_det, _, _, _ = pol.act(obs.cuda(), step=9, deterministic=True)
+    np.testing.assert_allclose(a_det.cpu().numpy(), mean.numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(pol.value(obs.cuda()).cpu().numpy(), val.numpy(), rtol=1e-5, atol=2e-6)
+    # time-limit bootstrap: reward += gamma V(terminal_obs) only where truncated and not terminated
+    term = (torch.rand(n) < 0.1).to(torch.uint8); trunc = (torch.rand(n) < 0.3).to(torch.uint8)
+    rew = torch.randn(n)
+    out = pol.bootstrap(obs.cuda(), term.cuda(), trunc.cuda(), 0.99, rew.clone().cuda()).cpu()
+    want = rew + 0.99 * val * ((trunc == 1) & (term == 0)).float()
+    np.testing.assert_allclose(out.numpy(), want.numpy(), rtol=1e-5, atol=2e-6)
+    pol.close(); pol2.close()
+
+
+@pytest.mark.gpu
+def test_gae_kernel_matches_the_sb3_recursion():
+    import torch
+    from balance_robot_mujoco_rl_amd.policy import gae
+    rng = np.random.default_rng(3)
+    T, N = 37, 1000
+    rew = rng.normal(size=(T, N)).astype(np.float32); val = rng.normal(size=(T, N)).astype(np.float32)
+    start = (rng.uniform(size=(T, N)) < 0.08).astype(np.uint8)
+    lv = rng.normal(size=N).astype(np.float32); ld = (rng.uniform(size=N) < 0.1).astype(np.uint8)
+    c = lambda a: torch.from_numpy(a).cuda()
+    adv, ret = gae(c(rew), c(val), c(start), c(lv), c(ld), 0.99, 0.95)
+    adv_ref, ret_ref = _ref_gae(rew, val, start, lv, ld, 0.99, 0.95)
+    np.testing.assert_allclose(adv.cpu().numpy(), adv_ref, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(ret.cpu().numpy(), ret_ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_device_rollout_runs_without_leaving_the_gpu_and_matches_a_stepwise_replay():
+    """DeviceRollout.collect (policy -> env step -> bootstrap, T times, then GAE) against the same sequence driven call
+    by call with torch ops for the bookkeeping: identical buffers (same kernels, same streams of noise)"""
+    import torch
+    from balance_robot_mujoco_rl_amd import BatchedSim
+    from balance_robot_mujoco_rl_amd.policy import DevicePolicy, DeviceRollout, NPARAM
+    n, T = 512, 24
+    flat = (np.random.default_rng(1).normal(size=NPARAM) * 0.2).astype(np.float32)
+    flat[-2:] = -0.5
+
+    def run(fused):
+        sim = BatchedSim("Env03-v2", n, seed=3, auto_reset=True, max_episode_steps=15)
+        pol = DevicePolicy(device=0, seed=11); pol.set_weights(flat)
+        if fused:
+            ro = DeviceRollout(sim, pol, T, gamma=0.97, gae_lambda=0.9).collect()
+            out = [x.clone() for x in (ro.obs, ro.action, ro.logp, ro.value, ro.reward, ro.episode_start, ro.adv, ro.ret)]
+        else:
+            obs = sim.reset().clone(); start = torch.ones(n, dtype=torch.uint8, device="cuda")
+            O_, A_, L_, V_, R_, S_ = [], [], [], [], [], []
+            for t in range(T):
+                a, ac, lp, v = pol.act(obs, step=t)
+                o2, r, te, tr, to = sim.step(ac)
+                r = r.clone() + 0.97 * pol.value(to) * ((tr == 1) & (te == 0)).float()
+                O_.append(obs.clone()); A_.append(a); L_.append(lp); V_.append(v); R_.append(r); S_.append(start.clone())
+                obs = o2.clone(); start = (te | tr).clone()
+            rew, val, st = torch.stack(R_), torch.stack(V_), torch.stack(S_)
+            adv_ref, ret_ref = _ref_gae(rew.cpu().numpy(), val.cpu().numpy(), st.cpu().numpy(), pol.value(obs).cpu().numpy(),
+                                        start.cpu().numpy(), 0.97, 0.9)
+            out = [torch.stack(O_), torch.stack(A_), torch.stack(L_), val, rew, st, torch.from_numpy(adv_ref).cuda(), torch.from_numpy(ret_ref).cuda()]
+        torch.cuda.synchronize()
+        sim.close(); pol.close()
+        return out
+
+    a, b = run(True), run(False)
+    for x, y, name in zip(a, b, ("obs", "action", "logp", "value", "reward", "episode_start", "adv", "ret")):
+        np.testing.assert_allclose(x.cpu().numpy().astype(np.float64), y.cpu().numpy().astype(np.float64), rtol=1e-5, atol=1e-5, err_msg=name)
+    assert int(a[5][1:].sum()) > 0, "episodes must end inside the rollout (time limit 15)"

@@ -31,7 +31,7 @@ int main(int argc, char** argv) {
     std::vector<Stats> per(N);
 #pragma omp parallel for schedule(dynamic, 4)
     for (int i = 0; i < N; i++) {
-      R buf[136];
+      R buf[LDS_WORDS_ENV03];
       Stream<R> rng; rng.open(P.seed, P.gid_base + i, 0u);
       Store<R> st{buf, 1}; int te, trn; float tob[6], rew;
       stats() = Stats{};

@@ -15,7 +15,7 @@ int main(int argc, char** argv) {
   Params<R> P = make_params<R>(3, true, -1, 0, 0, 0.0, 0, 0);
   std::vector<double> d(L::ND * (size_t)N); std::vector<R> f(L::NF * (size_t)N); std::vector<int> ii(L::NI * (size_t)N);
   hostconv::init_state<true>(d.data(), f.data(), ii.data(), N, 0, 0);
-  R buf[136];
+  R buf[LDS_WORDS_ENV03];
   std::vector<float> obs(6 * N);
   for (int i = 0; i < N; i++) {
     EnvState<R, true> S; load_state<R, true>(S, d.data(), f.data(), ii.data(), N, i);
