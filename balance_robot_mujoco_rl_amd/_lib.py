@@ -26,7 +26,7 @@ class BrsConfig(C.Structure):
                 ("substeps", C.c_int32), ("timestep", C.c_double), ("block_threads", C.c_int32), ("reserved", C.c_int32)]
 
 
-FLAG_AUTO_RESET, FLAG_NOISE_ON, FLAG_NOISE_OFF = 1, 2, 4
+FLAG_AUTO_RESET, FLAG_NOISE_ON, FLAG_NOISE_OFF, FLAG_NO_LANE_GROUPING = 1, 2, 4, 8
 
 
 def hipcc_path():

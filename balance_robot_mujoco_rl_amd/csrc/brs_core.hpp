@@ -814,10 +814,13 @@ template <typename R, bool BLK> struct Sim {
             R t0 = 0, t1 = 1;
             bool ok = true;
             const R pp[4] = {-du, du, -dv, dv}, qq[4] = {V[e][0] + ra, ra - V[e][0], V[e][1] + rb, rb - V[e][1]};
+            const bool zu = du == (R)0, zv = dv == (R)0;
+            const R idu = rcp_(zu ? (R)1 : du), idv = rcp_(zv ? (R)1 : dv);  // one reciprocal per direction, sign applied below
+            const R ip[4] = {-idu, idu, -idv, idv};
 #pragma unroll
             for (int b4 = 0; b4 < 4; b4++) {
-              const bool zero = pp[b4] == (R)0;
-              const R r = qq[b4] * rcp_(zero ? (R)1 : pp[b4]);
+              const bool zero = b4 < 2 ? zu : zv;
+              const R r = qq[b4] * ip[b4];
               ok = ok & !(zero & (qq[b4] < 0));
               t0 = (!zero & (pp[b4] < 0) & (r > t0)) ? r : t0;
               t1 = (!zero & (pp[b4] > 0) & (r < t1)) ? r : t1;
@@ -925,6 +928,9 @@ template <typename R, bool BLK> struct Sim {
       R d[3] = {cB[0] - wp[0], cB[1] - wp[1], cB[2] - wp[2]};
       R rr = P.wheel_brad + P.block_brad + c.margin;
       if (dot_(d, d) > rr * rr) continue;
+#ifdef BRS_NO_WHEELS
+      continue;  // ablation only
+#endif
       R best = c.margin, bpos[3] = {0, 0, 0}, bn[3] = {0, 0, 1}, wq[3] = {0, 0, 0};
       bool found = false;
       // (a) + (b): block points against the cylinder -- only the winning POINT is tracked in the loops (4 selects per

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -38,26 +39,60 @@ template <bool BLK> __device__ __forceinline__ Store<float> lane_store(float* ld
   return Store<float>{lds + wave * (64 * lane_words<BLK>()) + lane, 64};
 }
 
-template <bool BLK>
-__global__ void __launch_bounds__(256) brs_step_kernel(const Params<float> P, const int N, double* __restrict__ d,
+// VARIANT >= 0: the model constants of that registered id are folded at COMPILE time (constexpr make_params, default
+// timestep / substeps): ~100 values become instruction literals instead of SGPRs.  The kernel is SGPR-bound as well as
+// VGPR-bound -- with the constants in kernel arguments 5-15 % of its loop instructions were v_readlane reloads of spilled
+// SGPRs, each a VALU issue slot.  Only the per-handle fields stay runtime.  VARIANT = -1: everything runtime (non-default
+// timestep).
+template <int VARIANT> __device__ __forceinline__ Params<float> fold_params(const Params<float>& rt) {
+  if constexpr (VARIANT < 0) return rt;
+  else {
+    constexpr Params<float> c = make_params<float>(VARIANT, 0u, -1, 0, 0, 0.0, 0, 0);
+    Params<float> p = c;
+    p.seed = rt.seed; p.gid_base = rt.gid_base; p.auto_reset = rt.auto_reset; p.noise = rt.noise;
+    p.max_episode_steps = rt.max_episode_steps; p.nsub = rt.nsub;
+    return p;
+  }
+}
+
+template <bool BLK, int VARIANT>
+__global__ void __launch_bounds__(256) brs_step_kernel(const Params<float> Prt, const int N, double* __restrict__ d,
                                                        float* __restrict__ f, int* __restrict__ ii,
                                                        const float* __restrict__ actions, float* __restrict__ obs,
                                                        float* __restrict__ reward, uint8_t* __restrict__ terminated,
                                                        uint8_t* __restrict__ truncated, float* __restrict__ terminal_obs) {
   extern __shared__ float brs_lds_dyn[];
   float* lds = brs_lds_dyn;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;  // no barriers anywhere: a partial last wave just masks lanes
+  const int lane_slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (lane_slot >= N) return;  // no barriers anywhere: a partial last wave just masks lanes
+  const Params<float> P = fold_params<VARIANT>(Prt);
+  // lane <-> env: identity, or the cost-class grouping computed after the previous step (brs_state.hpp: cost_class).  The
+  // gather makes the state accesses of a wave non-contiguous; at < 0.2 % of the HBM roofline that costs nothing.  The env
+  // index is re-read wherever it is needed instead of being held across the loop (brs_state.hpp: LaneIndex).
+  // The map and the cost classes live behind the int state in the SAME allocation (ii + NI * N: perm[N], then keys[N] bytes):
+  // no extra kernel arguments -- the kernel is SGPR-bound too (its Params live in SGPRs), and two more pointers held across
+  // the loop cost ~10 % in spill traffic (measured).  Env01 has no rare collision paths: identity, decided at compile time.
+#if defined(BRS_NO_PERM)  // A/B builds only
+  const LaneIndex idx{nullptr, lane_slot};
+#else
+  const LaneIndex idx{BLK ? ii + (size_t)Layout<BLK>::NI * N : nullptr, lane_slot};
+#endif
   Store<float> st = lane_store<BLK>(lds);
 #if defined(BRS_TIMING) && defined(__HIP_DEVICE_COMPILE__)
   if ((threadIdx.x & 63) == 0) for (int k = 0; k < 16; k++) brs_tim_slots()[k] = 0;
 #endif
   Stream<float> rng;
-  rng.open(P.seed, P.gid_base + (int64_t)i, 0u);
-  const float a0 = actions[2 * (size_t)i], a1 = actions[2 * (size_t)i + 1];
+  float a0, a1;
+  {
+    const size_t i = idx.get();
+    rng.open(P.seed, P.gid_base + (int64_t)i, 0u);
+    a0 = actions[2 * i]; a1 = actions[2 * i + 1];
+  }
   float o[6], to[6], rew;
-  int te, tr;
-  env_step_mem<float, BLK, float>(P, st, rng, d, f, ii, (size_t)N, (size_t)i, a0, a1, o, to, rew, te, tr);
+  int te, tr, cls = 0;
+  env_step_idx<float, BLK, float, LaneIndex>(P, st, rng, d, f, ii, (size_t)N, idx, a0, a1, o, to, rew, te, tr, BLK ? &cls : nullptr);
+  const size_t i = idx.get();
+  if constexpr (BLK) ((uint8_t*)(ii + ((size_t)Layout<BLK>::NI + 1) * N))[i] = (uint8_t)cls;
 #if defined(BRS_TIMING) && defined(__HIP_DEVICE_COMPILE__)
   if ((threadIdx.x & 63) == 0) {
     for (int k = 0; k < 12; k++) atomicAdd(&brs_dbg[k], brs_tim_slots()[k]);
@@ -116,6 +151,47 @@ __global__ void __launch_bounds__(256) brs_physics_kernel(const Params<float> P,
   physics_mem<float, BLK, float>(P, st, d, f, ii, (size_t)N, (size_t)i, ctrl[2 * (size_t)i], ctrl[2 * (size_t)i + 1], nsub);
 }
 
+// stable counting sort of the envs by cost class (4 classes) -> perm[lane slot] = env.  ONE workgroup of 1024 threads: thread t
+// owns the contiguous chunk [t * per, (t + 1) * per) of envs; LDS holds the per-(class, thread) counts, scanned class-major.
+// 65,536 keys = 64 per thread: a few microseconds, once per env step.
+__global__ void __launch_bounds__(1024) brs_group_kernel(const int N, const uint8_t* __restrict__ keys, int* __restrict__ perm) {
+  __shared__ int cnt[4 * 1024];
+  const int t = threadIdx.x, per = (N + 1023) / 1024, lo = t * per, hi = min(N, lo + per);
+  int c[4] = {0, 0, 0, 0};
+  for (int e = lo; e < hi; e++) {
+    const int k = keys[e] & 3;
+    c[0] += k == 0; c[1] += k == 1; c[2] += k == 2; c[3] += k == 3;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) cnt[k * 1024 + t] = c[k];
+  __syncthreads();
+  // exclusive scan of the 4096 counts (class-major): Hillis-Steele over 4 values per thread
+  int v[4], sum = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) { v[k] = cnt[4 * t + k]; sum += v[k]; }
+  __shared__ int part[1024];
+  part[t] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int add = t >= off ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += add;
+    __syncthreads();
+  }
+  int run = part[t] - sum;
+#pragma unroll
+  for (int k = 0; k < 4; k++) { const int x = v[k]; cnt[4 * t + k] = run; run += x; }
+  __syncthreads();
+  int pos[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) pos[k] = cnt[k * 1024 + t];
+  for (int e = lo; e < hi; e++) {
+    const int k = keys[e] & 3;
+    const int p = k == 0 ? pos[0]++ : (k == 1 ? pos[1]++ : (k == 2 ? pos[2]++ : pos[3]++));
+    perm[p] = e;
+  }
+}
+
 thread_local std::string g_create_error;
 
 }  // namespace
@@ -128,6 +204,10 @@ struct brs_handle {
   float* f = nullptr;
   int* ii = nullptr;
   size_t nd = 0, nf = 0, ni = 0;
+  bool folded = false;       // model constants folded at compile time (default timestep): variant-specific step kernel
+  bool grouping = false;     // Env03: regroup lanes by cost class after every step (perm / keys live behind the int state)
+  int* perm() const { return ii + ni; }                            // [N] lane slot -> env
+  uint8_t* keys() const { return (uint8_t*)(ii + ni + (size_t)N); }  // [N] cost class of every env for its next step
   std::string err;
 };
 
@@ -216,9 +296,10 @@ int brs_create(const brs_config* cfg, brs_handle** out) {
   else { h->nd = Layout<false>::ND * N; h->nf = Layout<false>::NF * N; h->ni = Layout<false>::NI * N; }
   auto bail = [&](const std::string& m) { std::string mm = m; brs_destroy(h); return fail(nullptr, BRS_ERR_HIP, mm); };
   if (!g.ok) return bail("brs_create: hipSetDevice failed");
-  if (hipMalloc(&h->d, h->nd * sizeof(double)) != hipSuccess) return bail("brs_create: hipMalloc(fp64 state) failed");
+  // + 7 fp64 scratch columns addressed by lane slot (accessor pose parked during the last substep, brs_state.hpp: LaneIndex)
+  if (hipMalloc(&h->d, (h->nd + 7 * N) * sizeof(double)) != hipSuccess) return bail("brs_create: hipMalloc(fp64 state) failed");
   if (hipMalloc(&h->f, h->nf * sizeof(float)) != hipSuccess) return bail("brs_create: hipMalloc(fp32 state) failed");
-  if (hipMalloc(&h->ii, h->ni * sizeof(int)) != hipSuccess) return bail("brs_create: hipMalloc(int state) failed");
+  if (hipMalloc(&h->ii, (h->ni + 2 * N) * sizeof(int)) != hipSuccess) return bail("brs_create: hipMalloc(int state) failed");
   std::vector<double> d(h->nd);
   std::vector<float> f(h->nf);
   std::vector<int> ii(h->ni);
@@ -226,15 +307,24 @@ int brs_create(const brs_config* cfg, brs_handle** out) {
   if (h->blk) { hostconv::init_state<true>(d.data(), f.data(), ii.data(), N, cfg->seed, cfg->env_index_base); rc = upload_state<true>(h, d, f, ii); }
   else { hostconv::init_state<false>(d.data(), f.data(), ii.data(), N, cfg->seed, cfg->env_index_base); rc = upload_state<false>(h, d, f, ii); }
   if (rc != BRS_OK) return bail("brs_create: initial upload failed: " + h->err);
+  {  // lane map = identity until the first regrouping (always read by the Env03 step kernel)
+    std::vector<int> id(2 * N, 0);
+    for (size_t k = 0; k < N; k++) id[k] = (int)k;
+    if (hipMemcpy(h->perm(), id.data(), 2 * N * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return bail("brs_create: lane map init failed");
+    h->grouping = h->blk && !(cfg->flags & BRS_FLAG_NO_LANE_GROUPING);
+    h->folded = !(cfg->timestep > 0 && cfg->timestep != 2e-5) && !std::getenv("BRS_NO_FOLD");
+  }
   // dynamic LDS above the 64 KiB default needs the attribute (Env03, 256-thread blocks: 144 KiB)
   size_t lb = lds_bytes(h);
   hipError_t ea = hipSuccess;
+  auto want = [&](const void* fn) { if (ea == hipSuccess) ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb); };
   if (h->blk) {
-    ea = hipFuncSetAttribute((const void*)brs_step_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
-    if (ea == hipSuccess) ea = hipFuncSetAttribute((const void*)brs_physics_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+    want((const void*)brs_step_kernel<true, -1>); want((const void*)brs_step_kernel<true, ENV03_V1>);
+    want((const void*)brs_step_kernel<true, ENV03_V2>); want((const void*)brs_physics_kernel<true>);
   } else {
-    ea = hipFuncSetAttribute((const void*)brs_step_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
-    if (ea == hipSuccess) ea = hipFuncSetAttribute((const void*)brs_physics_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+    want((const void*)brs_step_kernel<false, -1>); want((const void*)brs_step_kernel<false, ENV01_V1>);
+    want((const void*)brs_step_kernel<false, ENV01_V2>); want((const void*)brs_step_kernel<false, ENV01_V3>);
+    want((const void*)brs_step_kernel<false, ENV02_V1>); want((const void*)brs_physics_kernel<false>);
   }
   if (ea != hipSuccess) return bail(std::string("brs_create: hipFuncSetAttribute: ") + hipGetErrorString(ea));
   *out = h;
@@ -274,12 +364,22 @@ int brs_step(brs_handle* h, const float* actions_dev, float* obs_dev, float* rew
   DeviceGuard g(h->device);
   hipStream_t s = (hipStream_t)stream;
   size_t lb = lds_bytes(h);
-  if (h->blk)
-    hipLaunchKernelGGL(brs_step_kernel<true>, dim3(grid_of(h)), dim3(h->bt), lb, s, h->P, h->N, h->d, h->f, h->ii, actions_dev,
-                       obs_dev, reward_dev, terminated_dev, truncated_dev, terminal_obs_dev);
-  else
-    hipLaunchKernelGGL(brs_step_kernel<false>, dim3(grid_of(h)), dim3(h->bt), lb, s, h->P, h->N, h->d, h->f, h->ii, actions_dev,
-                       obs_dev, reward_dev, terminated_dev, truncated_dev, terminal_obs_dev);
+  const dim3 grid(grid_of(h)), block(h->bt);
+#define BRS_LAUNCH_STEP(BLK_, VAR_)                                                                                          \
+  hipLaunchKernelGGL((brs_step_kernel<BLK_, VAR_>), grid, block, lb, s, h->P, h->N, h->d, h->f, h->ii, actions_dev, obs_dev, \
+                     reward_dev, terminated_dev, truncated_dev, terminal_obs_dev)
+  switch (h->folded ? h->P.variant : -1) {
+    case ENV01_V1: BRS_LAUNCH_STEP(false, ENV01_V1); break;
+    case ENV01_V2: BRS_LAUNCH_STEP(false, ENV01_V2); break;
+    case ENV01_V3: BRS_LAUNCH_STEP(false, ENV01_V3); break;
+    case ENV02_V1: BRS_LAUNCH_STEP(false, ENV02_V1); break;
+    case ENV03_V1: BRS_LAUNCH_STEP(true, ENV03_V1); break;
+    case ENV03_V2: BRS_LAUNCH_STEP(true, ENV03_V2); break;
+    default:
+      if (h->blk) BRS_LAUNCH_STEP(true, -1); else BRS_LAUNCH_STEP(false, -1);
+  }
+#undef BRS_LAUNCH_STEP
+  if (h->grouping) hipLaunchKernelGGL(brs_group_kernel, dim3(1), dim3(1024), 0, s, h->N, h->keys(), h->perm());  // lanes of the NEXT step
   BRS_HIP_TRY(h, hipGetLastError());
   return BRS_OK;
 }
@@ -354,7 +454,7 @@ int brs_debug_counters(unsigned long long* out16) {
 #endif
 const char* brs_step_kernel_name(const brs_handle* h) {
   if (!h) return "";
-  return h->blk ? "brs_step_kernel<true>" : "brs_step_kernel<false>";
+  return h->blk ? "brs_step_kernel<true" : "brs_step_kernel<false";  // (prefix: the variant is a second template argument)
 }
 
 }  // extern "C"

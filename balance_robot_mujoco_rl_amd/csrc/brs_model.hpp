@@ -72,9 +72,22 @@ struct ModelRaw {
   double h = 0.00002, g = 9.81;
 };
 
+// constexpr square root (Newton): make_params is evaluated at COMPILE time for the step kernels (brs_kernels.hip), so that
+// the ~100 model constants become instruction literals instead of SGPRs that spill
+constexpr double csqrt(double x) {
+  if (!(x > 0)) return 0;
+  double r = x > 1 ? x : 1.0;
+  for (int k = 0; k < 200; k++) {
+    const double n = 0.5 * (r + x / r);
+    if (n == r) break;
+    r = n;
+  }
+  return r;
+}
+
 // solve (M_b + diag(0,..,0,dL,dR)) x = f for the robot's 8 dofs in body coordinates
 // order: [alpha_x, alpha_y, alpha_z, wdot_x, wdot_y, wdot_z, wdot_L, wdot_R]
-inline void msolve_d(double m, double cz, double Ixx, double Iyy, double Izz, double Ia, const double* f, double dL,
+constexpr void msolve_d(double m, double cz, double Ixx, double Iyy, double Izz, double Ia, const double* f, double dL,
                      double dR, double* x) {
   double mcz = m * cz, det = m * Iyy - mcz * mcz;
   x[2] = f[2] / m;
@@ -90,7 +103,7 @@ inline void msolve_d(double m, double cz, double Ixx, double Iyy, double Izz, do
 }
 
 template <typename R>
-inline Params<R> make_params(int variant, uint32_t flags_auto_reset, int noise_override /* -1 default, 0 off, 1 on */,
+constexpr Params<R> make_params(int variant, uint32_t flags_auto_reset, int noise_override /* -1 default, 0 off, 1 on */,
                              int max_episode_steps, int nsub, double timestep, uint64_t seed, int64_t gid_base) {
   const double PI = 3.14159265358979323846;
   ModelRaw r;
@@ -119,21 +132,22 @@ inline Params<R> make_params(int variant, uint32_t flags_auto_reset, int noise_o
   p.kv = (R)r.kv; p.ctrlrange = (R)r.ctrlrange; p.forcerange = (R)r.forcerange; p.damping = (R)r.damping;
   double mB = 8 * r.block_s * r.block_s * r.block_s * r.density, IB = mB / 3 * 2 * r.block_s * r.block_s;
   p.mB = (R)mB; p.IB = (R)IB; p.block_s = (R)r.block_s; p.inv_mB = (R)(1 / mB); p.inv_IB = (R)(1 / IB);
-  p.torso_brad = (R)std::sqrt(r.torso_s[0] * r.torso_s[0] + r.torso_s[1] * r.torso_s[1] + r.torso_s[2] * r.torso_s[2]);
-  p.block_brad = (R)(r.block_s * std::sqrt(3.0));
-  p.wheel_brad = (R)std::sqrt(r.wheel_r * r.wheel_r + r.wheel_hl * r.wheel_hl);
+  p.torso_brad = (R)csqrt(r.torso_s[0] * r.torso_s[0] + r.torso_s[1] * r.torso_s[1] + r.torso_s[2] * r.torso_s[2]);
+  p.block_brad = (R)(r.block_s * csqrt(3.0));
+  p.wheel_brad = (R)csqrt(r.wheel_r * r.wheel_r + r.wheel_hl * r.wheel_hl);
 
   // body_invweight0 (translational), as MuJoCo computes it at qpos0: mean diagonal of Jp M^-1 Jp^T at the body COM
   auto tran_of = [&](double rx, double ry, double rz, int wheel /*0 none, 1 L, 2 R*/) {
     // COM Jacobian rows (body coordinates, R = I at qpos0): e_k | (r x e_k)... row k = [e_k, r x e_k, 0, 0]
     // a wheel's COM lies on its hinge axis: the hinge column is zero
     (void)wheel;
-    double tr = 0, rr[3] = {rx, ry, rz};
+    double tr = 0;
+    const double rr[3] = {rx, ry, rz};
     for (int k = 0; k < 3; k++) {
       double e[3] = {0, 0, 0};
       e[k] = 1;
       double rowv[8] = {e[0], e[1], e[2], rr[1] * e[2] - rr[2] * e[1], rr[2] * e[0] - rr[0] * e[2], rr[0] * e[1] - rr[1] * e[0], 0, 0};
-      double x[8];
+      double x[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       msolve_d(m, cz, Ixx, Iyy, Izz, Ia, rowv, 0, 0, x);
       for (int j = 0; j < 8; j++) tr += rowv[j] * x[j];
     }
@@ -145,7 +159,7 @@ inline Params<R> make_params(int variant, uint32_t flags_auto_reset, int noise_o
 
   int family = (variant == ENV03_V1 || variant == ENV03_V2) ? 3 : 1;
   auto mk = [&](double mu, double tc, double dr, double d0, double d1, double width, double margin, double tran) {
-    ContactClass<R> c;
+    ContactClass<R> c{};
     if (tc < 2 * h) tc = 2 * h;  // refsafe
     c.mu = (R)mu;
     c.K = (R)(1.0 / (d1 * d1 * tc * tc * dr * dr));

@@ -110,22 +110,76 @@ BRS_HD void store_state(const EnvState<R, BLK>& S, double* d, FT* f, int* ii, si
   ii[L::I_BAD * N + i] = S.bad;
 }
 
+// Cost class of an env for its NEXT step (Env03): which of the rare, expensive collision paths it is likely to walk.
+//   bit 0: the block can reach the floor within one env step          (plane<->box path + block<->floor rows in the solver)
+//   bit 1: the block can reach a wheel within one env step            (box<->cylinder closest-feature path)
+// A wave pays for a path whenever ONE of its 64 lanes walks it, and with one wave per SIMD a launch lasts as long as its
+// slowest wave: brs_step therefore groups envs of one class into the same waves (a permutation env <-> lane, recomputed
+// after every step from these keys).  Purely a scheduling hint: an env's arithmetic does not depend on its lane, a wrong
+// guess only costs time.  Conservative reach tests: speed x step time + 3 mm.
+template <typename R, bool BLK> BRS_HD int cost_class(const Params<R>& P, const EnvState<R, BLK>& S) {
+  if constexpr (!BLK) return 0;
+  else {
+    const R T = (R)P.nsub * P.h, slack = (R)0.003;
+    const R vb = sqrt_(S.bv[0] * S.bv[0] + S.bv[1] * S.bv[1] + S.bv[2] * S.bv[2]);
+    const R vr = sqrt_(S.v[0] * S.v[0] + S.v[1] * S.v[1] + S.v[2] * S.v[2]) + (R)0.12 * sqrt_(S.w[0] * S.w[0] + S.w[1] * S.w[1] + S.w[2] * S.w[2]);
+    const R reach = (vb + vr) * T + (R)0.5 * P.g * T * T + slack;
+    int key = 0;
+    const R low = (R)(S.bp[2] - P.floor_z_d) - P.block_brad - P.cc[CC_BLOCK_FLOOR].margin;
+    key |= low < reach ? 1 : 0;
+    R qf[4] = {(R)S.q[0], (R)S.q[1], (R)S.q[2], (R)S.q[3]}, RT[9];
+    quat2mat_(qf, RT);
+    const R d[3] = {(R)(S.bp[0] - S.p[0]), (R)(S.bp[1] - S.p[1]), (R)(S.bp[2] - S.p[2])};
+    R dl[3];
+    mulT_(RT, d, dl);  // block centre in the torso frame
+    const R rr = P.wheel_brad + P.block_brad + P.cc[CC_BLOCK_ROBOT].margin + reach;
+    const R dz = dl[2] - P.wheel_pz, dxl = dl[0] + P.wheel_px, dxr = dl[0] - P.wheel_px;
+    const R base = dl[1] * dl[1] + dz * dz;
+    key |= (base + dxl * dxl < rr * rr || base + dxr * dxr < rr * rr) ? 2 : 0;
+    return key;
+  }
+}
+
 // One full env step working from / to the SoA state in memory (the HIP step kernel's body; the host test build runs
 // the same function).  Register diet for the 250-substep loop: the accessor pose of the LAST forward pass is written
 // straight to its HBM slot when the last substep starts and read back afterwards, and the env-level scalars are only
 // loaded after the loop -- neither is live while the solver needs every VGPR.
-template <typename R, bool BLK, typename FT>
-BRS_HD void env_step_mem(const Params<R>& P, Store<R>& st, Stream<R>& rng, double* d, FT* f, int* ii, size_t N, size_t i,
-                         float a0, float a1, float* obs, float* terminal_obs, float& reward, int& terminated, int& truncated) {
+// Where the env index of a lane comes from.  With lane grouping (brs_kernels.hip) it is a LOADED value (perm[lane slot]);
+// kept in a register across the 250-substep loop it would cost two VGPRs the solver does not have (measured: +10 % VALU
+// instructions from the extra register shuffling).  Every use therefore asks again: a volatile load, one L2 hit.
+// The one indexed access INSIDE the loop -- parking the accessor pose when the last substep starts -- goes to a scratch
+// column addressed by the LANE SLOT (affine in the thread id: SGPR base + one VGPR offset, as cheap as before the grouping);
+// 7 extra fp64 fields behind the state (Layout::ND + j).  FixedIndex (host build, tests) parks it in the env's own fields.
+struct FixedIndex {
+  static constexpr bool SCRATCH = false;
+  size_t i;
+  BRS_HD size_t get() const { return i; }
+  BRS_HD size_t slot_index() const { return i; }
+};
+struct LaneIndex {
+  static constexpr bool SCRATCH = true;
+  const volatile int* perm;  // nullptr = identity
+  int slot;
+  BRS_HD size_t get() const { return perm ? (size_t)perm[slot] : (size_t)slot; }
+  BRS_HD size_t slot_index() const { return (size_t)slot; }
+};
+
+template <typename R, bool BLK, typename FT, typename IDX>
+BRS_HD void env_step_idx(const Params<R>& P, Store<R>& st, Stream<R>& rng, double* d, FT* f, int* ii, size_t N, const IDX& idx,
+                         float a0, float a1, float* obs, float* terminal_obs, float& reward, int& terminated, int& truncated,
+                         int* next_cost_class = nullptr) {
   using L = Layout<BLK>;
   using SimT = Sim<R, BLK>;
   EnvState<R, BLK> S;
-  load_state_phys<R, BLK, FT>(S, d, f, ii, N, i);
-  load_state_env<R, BLK, FT>(S, d, f, ii, N, i);  // re-loaded after the loop: not live across it
-  rng.ctr = S.rng_ctr;
-  R ctrlL, ctrlR;
-  R rew = SimT::env_pre(P, S, rng, a0, a1, ctrlL, ctrlR);
-  if (P.v3) f[L::F_TWS * N + i] = (FT)S.tws;  // the schedule may have moved the target
+  R ctrlL, ctrlR, rew;
+  {
+    const size_t i = idx.get();
+    load_state_phys<R, BLK, FT>(S, d, f, ii, N, i);
+    load_state_env<R, BLK, FT>(S, d, f, ii, N, i);  // re-loaded after the loop: not live across it
+    rng.ctr = S.rng_ctr;
+    rew = SimT::env_pre(P, S, rng, a0, a1, ctrlL, ctrlR);
+    if (P.v3) f[L::F_TWS * N + i] = (FT)S.tws;  // the schedule may have moved the target
+  }
   {  // flattened substep x Newton loop: one trip = [start a substep] + [one Newton iteration] + [finish the substep]
     typename SimT::SubCtx C;
     int k = 0;
@@ -134,10 +188,12 @@ BRS_HD void env_step_mem(const Params<R>& P, Store<R>& st, Stream<R>& rng, doubl
       BRS_TIC(8);
       if (fresh) {
         if (k == P.nsub - 1) {
+          const size_t sl = idx.slot_index();
+          constexpr int FQ = IDX::SCRATCH ? L::ND : L::D_XQ, FP = IDX::SCRATCH ? L::ND + 4 : L::D_XP;
 #pragma unroll
-          for (int j = 0; j < 4; j++) d[(L::D_XQ + j) * N + i] = S.q[j];
+          for (int j = 0; j < 4; j++) d[(FQ + j) * N + sl] = S.q[j];
 #pragma unroll
-          for (int j = 0; j < 3; j++) d[(L::D_XP + j) * N + i] = S.p[j];
+          for (int j = 0; j < 3; j++) d[(FP + j) * N + sl] = S.p[j];
         }
         SimT::sub_begin(P, st, S, ctrlL, ctrlR, C);
         fresh = false;
@@ -157,16 +213,28 @@ BRS_HD void env_step_mem(const Params<R>& P, Store<R>& st, Stream<R>& rng, doubl
 #if defined(__HIP_DEVICE_COMPILE__)
   asm volatile("" ::: "memory");  // re-read the pose from memory: do not keep it in registers across the loop
 #endif
+  const size_t i = idx.get();
+  rng.gid = P.gid_base + (int64_t)i;  // (same value as before the loop: recomputed so that it is not live across it)
   if (P.nsub > 0) {
+    const size_t sl = idx.slot_index();
+    constexpr int FQ = IDX::SCRATCH ? L::ND : L::D_XQ, FP = IDX::SCRATCH ? L::ND + 4 : L::D_XP;
 #pragma unroll
-    for (int j = 0; j < 4; j++) S.xq[j] = d[(L::D_XQ + j) * N + i];
+    for (int j = 0; j < 4; j++) S.xq[j] = d[(FQ + j) * N + sl];
 #pragma unroll
-    for (int j = 0; j < 3; j++) S.xp[j] = d[(L::D_XP + j) * N + i];
+    for (int j = 0; j < 3; j++) S.xp[j] = d[(FP + j) * N + sl];
   }
   load_state_env<R, BLK, FT>(S, d, f, ii, N, i);
   SimT::env_post(P, S, rng, rew, obs, terminal_obs, reward, terminated, truncated);
   S.rng_ctr = rng.ctr;
+  if (next_cost_class) *next_cost_class = cost_class<R, BLK>(P, S);
   store_state<R, BLK, FT>(S, d, f, ii, N, i);
+}
+template <typename R, bool BLK, typename FT>
+BRS_HD void env_step_mem(const Params<R>& P, Store<R>& st, Stream<R>& rng, double* d, FT* f, int* ii, size_t N, size_t i,
+                         float a0, float a1, float* obs, float* terminal_obs, float& reward, int& terminated, int& truncated,
+                         int* next_cost_class = nullptr) {
+  env_step_idx<R, BLK, FT, FixedIndex>(P, st, rng, d, f, ii, N, FixedIndex{i}, a0, a1, obs, terminal_obs, reward, terminated, truncated,
+                                       next_cost_class);
 }
 
 // physics only (parity tests): nsub substeps with ctrl held, same flattened loop

@@ -24,7 +24,7 @@ class BatchedSim:
     all CUDA(=HIP) tensors owned by this object and overwritten by the next call (no allocation per step)."""
 
     def __init__(self, env_id, num_envs, device=0, seed=0, env_index_base=0, auto_reset=True, obs_noise=None,
-                 max_episode_steps=0, substeps=0, timestep=0.0, block_threads=0):
+                 max_episode_steps=0, substeps=0, timestep=0.0, block_threads=0, lane_grouping=True):
         self.spec = spec(env_id)
         if not torch.cuda.is_available():
             raise BrsError("no HIP device visible to PyTorch: the batched simulator has no CPU fallback")
@@ -35,6 +35,8 @@ class BatchedSim:
             flags |= _lib.FLAG_NOISE_ON
         elif obs_noise is False:
             flags |= _lib.FLAG_NOISE_OFF
+        if not lane_grouping:
+            flags |= _lib.FLAG_NO_LANE_GROUPING
         cfg = _lib.BrsConfig(self.spec.variant, int(num_envs), self.device.index, flags, int(seed), int(env_index_base),
                              int(max_episode_steps), int(substeps), float(timestep), int(block_threads), 0)
         h = C.c_void_p()

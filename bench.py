@@ -114,6 +114,7 @@ def main():
                          "drop, no contacts, first block in flight); the pre-roll runs until falls and auto-resets have "
                          "de-phased them and the per-step kernel time is stationary")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-lane-grouping", action="store_true", help="A/B: keep env i on lane i (BRS_FLAG_NO_LANE_GROUPING)")
     args = ap.parse_args()
 
     env_world = os.environ.get("WORLD_SIZE")
@@ -151,7 +152,7 @@ def main():
     from balance_robot_mujoco_rl_amd import BatchedSim
     n = args.envs
     sim = BatchedSim(args.env, n, device=dev.index, seed=0, env_index_base=rank * n, auto_reset=True,
-                     block_threads=args.block_threads)
+                     block_threads=args.block_threads, lane_grouping=not args.no_lane_grouping)
     sim.reset()
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
@@ -214,7 +215,7 @@ def main():
             "config": {"workload": f"{args.env}, {n} env instances per GPU ({total_envs} total), random policy "
                                    f"U(-1,1)^2, auto-reset on, 250 substeps of 2e-5 s per env step",
                        "envs_per_gpu": n, "substeps": 250, "parallelism": f"env-sharded x{world}, no collective",
-                       "preroll_steps": preroll, "preroll_window_ms_per_step": [round(x, 4) for x in win_ms]},
+                       "lane_grouping": not args.no_lane_grouping, "preroll_steps": preroll, "preroll_window_ms_per_step": [round(x, 4) for x in win_ms]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": sim.step_kernel_name(), "kernel_ms": kern_ms,

@@ -50,7 +50,9 @@ typedef enum {
 enum {
   BRS_FLAG_AUTO_RESET = 1u, /* SB3 VecEnv semantics: a done env is reset inside brs_step, obs = first obs of the new episode */
   BRS_FLAG_NOISE_ON = 2u,   /* force observation noise on  (default: on for Env01-v2 only, as in the reference) */
-  BRS_FLAG_NOISE_OFF = 4u   /* force observation noise off */
+  BRS_FLAG_NOISE_OFF = 4u,  /* force observation noise off */
+  BRS_FLAG_NO_LANE_GROUPING = 8u /* keep env i on lane i (default: brs_step regroups the envs of a handle by collision cost
+                                    class after every step -- a scheduling matter only, results are bit-identical) */
 };
 
 typedef struct {
