@@ -198,3 +198,22 @@ def test_solver_stationarity_on_random_contact_states():
             checked += 1
             with_coupled += any(c["body2"] == 4 and c["body1"] != 0 for c in f["contacts"])
     assert checked > 100 and with_coupled > 0
+
+
+def test_block_cannot_touch_both_wheels_at_once():
+    """the kernel tests the block against ONE wheel, the one on its side of the robot (brs_core.hpp collide_coupled (ii)):
+    the gap between the wheels' inner faces exceeds the block's diameter plus twice the contact margin
+    (ref:envs/robot-02.xml:9-18 wheel positions / sizes, ref:envs/env03_v1.xml:31-37 block size / margin)"""
+    wheel_px, wheel_hl, block_s, margin = 0.074, 0.013, 0.02, 0.002
+    gap = 2 * (wheel_px - wheel_hl)
+    assert gap > 2 * (block_s * np.sqrt(3.0) + margin) + 0.04
+    # and the oracle agrees on states with the block between the wheels: never two wheel contacts
+    rng = np.random.default_rng(4)
+    o = O.Oracle("Env03-v2", 1)
+    for _ in range(300):
+        q = np.zeros((1, 16)); q[0, 3] = 1; q[0, 2] = 1.0
+        bq = rng.normal(size=4); q[0, 12:16] = bq / np.linalg.norm(bq)
+        q[0, 9:12] = [rng.uniform(-0.09, 0.09), rng.uniform(-0.06, 0.06), 1.0 + rng.uniform(-0.02, 0.09)]
+        o.set_state(q, np.zeros((1, 14)))
+        wheels = {c["body1"] for c in o.forward()["contacts"] if c["body2"] == 4 and c["body1"] in (2, 3)}
+        assert len(wheels) <= 1
