@@ -21,4 +21,15 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_W
 done
 cd $ROOT
 python3 tools/summarise_profile.py $OUT $ENVARG > $OUT/summary.json
+# the rocpd databases are tens of MB each (gpurun merges at most 64 MiB back): keep the summary and the kernel-trace table only
+python3 - "$OUT" <<'PY'
+import sqlite3, sys, csv, os
+out = sys.argv[1]
+con = sqlite3.connect(os.path.join(out, "trace", "trace_results.db"))
+with open(os.path.join(out, "kernel_stats.csv"), "w", newline="") as f:
+    w = csv.writer(f); w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage"])
+    for r in con.execute("select * from top_kernels"):
+        w.writerow([r[0][:120], r[1], r[2], r[3], r[4]])
+PY
+rm -rf $OUT/trace $OUT/pmc_*/
 cat $OUT/summary.json
