@@ -26,7 +26,8 @@ if os.path.exists(tr):
         res["kernel_trace_ms"] = {"dispatches": len(d), "timed_300_mean": float(tail.mean()), "timed_300_median": float(np.median(tail)),
                                   "timed_300_min": float(tail.min()), "timed_300_max": float(tail.max()),
                                   "first_20_after_reset_mean": float(np.mean(d[:20])), "all_mean": float(np.mean(d))}
-    vg = list(con.execute("select kernel_name, sgpr_count, arch_vgpr_count, private_segment_size, group_segment_size from kernel_symbols where kernel_name like '%brs_step_kernel%'"))
+    ran = {r[0] for r in con.execute("select distinct name from kernels where name like '%brs_step_kernel%'")}
+    vg = [r for r in con.execute("select kernel_name, sgpr_count, arch_vgpr_count, private_segment_size, group_segment_size, display_name from kernel_symbols where kernel_name like '%brs_step_kernel%'") if r[5] in ran or r[0] in ran]
     if vg:
         res["kernel_symbol"] = dict(name=vg[0][0][:80], sgpr=vg[0][1], arch_vgpr=vg[0][2], scratch_bytes_per_lane=vg[0][3], static_lds=vg[0][4])
 pmc = {}
