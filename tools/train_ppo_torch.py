@@ -16,6 +16,15 @@ sys.path.insert(0, ROOT)
 from balance_robot_mujoco_rl_amd import BatchedSim
 
 
+def flat_params(model):
+    """the ActorCritic's parameters in the order of include/brs_policy.h (one device tensor, no host copy); the critic's
+    output unit `ret_scale` is folded into its last layer"""
+    p, v = model.pi, model.v
+    parts = [p[0].weight, p[0].bias, p[2].weight, p[2].bias, p[4].weight, p[4].bias,
+             v[0].weight, v[0].bias, v[2].weight, v[2].bias, v[4].weight * model.ret_scale, v[4].bias * model.ret_scale, model.log_std]
+    return torch.cat([t.detach().reshape(-1) for t in parts]).contiguous()
+
+
 class ActorCritic(nn.Module):
     def __init__(self, log_std_init=-0.5):
         super().__init__()
@@ -77,9 +86,15 @@ class MixedSim:
 
 
 def train(sim, model, opt, iters, n_steps, epochs, minibatch, gamma, lam, clip, log, tag, ent=0.0, reward_clip=None,
-          critic_warmup=0, lr_end=None, norm_returns=False, target_kl=None):
+          critic_warmup=0, lr_end=None, norm_returns=False, target_kl=None, device_rollout=False, seed=0, env_index_base=0):
     n = sim.n
     dev = sim.device
+    pol = None
+    if device_rollout:   # rollout side on the HIP kernels of include/brs_policy.h (forward + sample, bootstrap, GAE)
+        from balance_robot_mujoco_rl_amd.policy import DevicePolicy, gae as gae_kernel
+        pol = DevicePolicy(device=dev.index, seed=seed, env_index_base=env_index_base)
+        a_buf = torch.zeros((n, 2), device=dev); start = torch.ones(n, dtype=torch.uint8, device=dev)
+        S = torch.zeros((n_steps, n), dtype=torch.uint8, device=dev); gstep = 0
     obs = sim.reset().clone()
     ep_len = torch.zeros(n, device=dev); ep_ret = torch.zeros(n, device=dev)
     done_len_sum = done_ret_sum = done_cnt = 0.0
@@ -91,31 +106,45 @@ def train(sim, model, opt, iters, n_steps, epochs, minibatch, gamma, lam, clip, 
             for g_ in opt.param_groups:
                 g_["lr"] = lr0 + (lr_end - lr0) * it / max(1, iters - 1)
         with torch.no_grad():
+            if pol is not None:
+                fp = flat_params(model); pol.use_device_weights(fp)   # the learner's current weights, read in place
             for t in range(n_steps):
-                d = model.dist(obs)
-                a = d.sample()
-                B["obs"][t] = obs; B["act"][t] = a; B["logp"][t] = d.log_prob(a).sum(-1); B["val"][t] = model.value(obs)
-                o, r, te, tr, to = sim.step(a.clamp(-1, 1).contiguous())   # SB3 clips actions to the Box before env.step
-                done = (te | tr).bool()
-                # time-limit truncation (not a failure): bootstrap from the terminal observation, like SB3
-                boot = torch.where(tr.bool() & ~te.bool(), model.value(to), torch.zeros_like(r))
-                # learner-side reward clipping (a TransformReward-style wrapper); logged returns stay the env's own
-                B["rew"][t] = r if reward_clip is None else r.clamp(max=reward_clip)
-                B["done"][t] = done.float(); B["boot"][t] = boot
+                if pol is not None:
+                    B["obs"][t] = obs; S[t] = start
+                    pol.act(B["obs"][t], gstep, out=(B["act"][t], a_buf, B["logp"][t], B["val"][t])); gstep += 1
+                    o, r, te, tr, to = sim.step(a_buf)
+                    done = (te | tr).bool()
+                    B["rew"][t] = r if reward_clip is None else r.clamp(max=reward_clip)
+                    pol.bootstrap(to, te, tr, gamma, B["rew"][t])   # rew += gamma V(terminal_obs) where truncated only
+                    B["done"][t] = done.float(); start = (te | tr).clone()
+                else:
+                    d = model.dist(obs)
+                    a = d.sample()
+                    B["obs"][t] = obs; B["act"][t] = a; B["logp"][t] = d.log_prob(a).sum(-1); B["val"][t] = model.value(obs)
+                    o, r, te, tr, to = sim.step(a.clamp(-1, 1).contiguous())   # SB3 clips actions to the Box before env.step
+                    done = (te | tr).bool()
+                    # time-limit truncation (not a failure): bootstrap from the terminal observation, like SB3
+                    boot = torch.where(tr.bool() & ~te.bool(), model.value(to), torch.zeros_like(r))
+                    # learner-side reward clipping (a TransformReward-style wrapper); logged returns stay the env's own
+                    B["rew"][t] = r if reward_clip is None else r.clamp(max=reward_clip)
+                    B["done"][t] = done.float(); B["boot"][t] = boot
                 ep_len += 1; ep_ret += r
                 if done.any():
                     done_len_sum += ep_len[done].sum().item(); done_ret_sum += ep_ret[done].sum().item(); done_cnt += done.sum().item()
                     ep_len[done] = 0; ep_ret[done] = 0
                 obs = o.clone()
-            last_v = model.value(obs)
-            adv = torch.zeros_like(B["rew"]); g = torch.zeros(n, device=dev)
-            for t in reversed(range(n_steps)):
-                nv = last_v if t == n_steps - 1 else B["val"][t + 1]
-                nonterm = 1.0 - B["done"][t]
-                delta = B["rew"][t] + gamma * (nv * nonterm + B["boot"][t]) - B["val"][t]
-                g = delta + gamma * lam * nonterm * g
-                adv[t] = g
-            ret = adv + B["val"]
+            if pol is not None:
+                adv, ret = gae_kernel(B["rew"], B["val"], S, pol.value(obs), start, gamma, lam)
+            else:
+                last_v = model.value(obs)
+                adv = torch.zeros_like(B["rew"]); g = torch.zeros(n, device=dev)
+                for t in reversed(range(n_steps)):
+                    nv = last_v if t == n_steps - 1 else B["val"][t + 1]
+                    nonterm = 1.0 - B["done"][t]
+                    delta = B["rew"][t] + gamma * (nv * nonterm + B["boot"][t]) - B["val"][t]
+                    g = delta + gamma * lam * nonterm * g
+                    adv[t] = g
+                ret = adv + B["val"]
             if norm_returns:
                 model.ret_scale.lerp_(_allreduce_mean_(ret.std()).clamp(min=1.0), 0.05 if it else 1.0)   # same on all ranks
         flat = {k: v.reshape((-1,) + v.shape[2:]) for k, v in B.items()}
@@ -212,6 +241,8 @@ def main():
     ap.add_argument("--reward-clip", type=float, default=None, help="learner-side upper clip of the per-step reward")
     ap.add_argument("--eval-steps", type=int, default=0, help="after training: deterministic evaluation for this many steps")
     ap.add_argument("--eval-envs", type=int, default=4096)
+    ap.add_argument("--device-rollout", action="store_true",
+                    help="act, bootstrap and GAE with the HIP kernels of include/brs_policy.h instead of torch ops")
     ap.add_argument("--save", default="", help="write the policy/value weights (torch state_dict) here")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
@@ -254,7 +285,7 @@ def main():
         else:
             sim = BatchedSim(env_id, a.envs, device=local, seed=2 * a.seed, env_index_base=base, auto_reset=True)
         train(sim, model, opt, iters, a.n_steps, a.epochs, a.minibatch, a.gamma, a.lam, 0.2, log, env_id, a.ent, a.reward_clip,
-              warm, a.lr2_end if phase == 1 else None, a.norm_returns, a.target_kl)
+              warm, a.lr2_end if phase == 1 else None, a.norm_returns, a.target_kl, a.device_rollout, 1000 * (a.seed + 1) + phase, base)
         sim.close()
     evals = []
     if world > 1:
