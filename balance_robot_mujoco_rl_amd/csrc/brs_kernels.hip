@@ -158,8 +158,15 @@ __global__ void __launch_bounds__(1024) brs_group_kernel(const int N, const uint
   __shared__ int cnt[4 * 1024];
   const int t = threadIdx.x, per = (N + 1023) / 1024, lo = t * per, hi = min(N, lo + per);
   int c[4] = {0, 0, 0, 0};
+  // bucket order along the lanes: floor class, plain, wheel class, both -- the boundary waves then mix (floor | plain) and
+  // (plain | wheel), i.e. cost no more than a pure rare-class wave; (floor | wheel) side by side would pay for both paths
+#if defined(BRS_CLASS_V1)
+#define BRS_BUCKET(k_) (k_)
+#else
+#define BRS_BUCKET(k_) ((k_) == 0 ? 1 : ((k_) == 1 ? 0 : (k_)))
+#endif
   for (int e = lo; e < hi; e++) {
-    const int k = keys[e] & 3;
+    const int k = BRS_BUCKET(keys[e] & 3);
     c[0] += k == 0; c[1] += k == 1; c[2] += k == 2; c[3] += k == 3;
   }
 #pragma unroll
@@ -186,7 +193,7 @@ __global__ void __launch_bounds__(1024) brs_group_kernel(const int N, const uint
 #pragma unroll
   for (int k = 0; k < 4; k++) pos[k] = cnt[k * 1024 + t];
   for (int e = lo; e < hi; e++) {
-    const int k = keys[e] & 3;
+    const int k = BRS_BUCKET(keys[e] & 3);
     const int p = k == 0 ? pos[0]++ : (k == 1 ? pos[1]++ : (k == 2 ? pos[2]++ : pos[3]++));
     perm[p] = e;
   }

@@ -126,7 +126,12 @@ template <typename R, bool BLK> BRS_HD int cost_class(const Params<R>& P, const 
     const R reach = (vb + vr) * T + (R)0.5 * P.g * T * T + slack;
     int key = 0;
     const R low = (R)(S.bp[2] - P.floor_z_d) - P.block_brad - P.cc[CC_BLOCK_FLOOR].margin;
+#if defined(BRS_CLASS_V1)
     key |= low < reach ? 1 : 0;
+#else
+    // only the block's DOWNWARD speed brings it to the floor (its orientation is covered by the bounding radius)
+    key |= low < max_(-S.bv[2], (R)0) * T + (R)0.5 * P.g * T * T + slack ? 1 : 0;
+#endif
     R qf[4] = {(R)S.q[0], (R)S.q[1], (R)S.q[2], (R)S.q[3]}, RT[9];
     quat2mat_(qf, RT);
     const R d[3] = {(R)(S.bp[0] - S.p[0]), (R)(S.bp[1] - S.p[1]), (R)(S.bp[2] - S.p[2])};

@@ -1,7 +1,9 @@
-mkdir -p gpurun_out/ppo_r02
-# config 5 smoke: ONE fixed recipe (round 1's Env01-v1 recipe), rollouts on the HIP policy / bootstrap / GAE kernels
-python tools/train_ppo_torch.py --env Env01-v1 --envs 16384 --iters 60 --n-steps 64 --epochs 4 --minibatch 8192 --lr 3e-4 --gamma 0.999 --reward-clip 1.0 --device-rollout --eval-steps 1500 --out gpurun_out/ppo_r02/env01_v1_device_rollout.json > gpurun_out/ppo_r02/device.log 2>&1
-tail -4 gpurun_out/ppo_r02/device.log | cut -c1-400
-# the same recipe with the torch rollout (round 1's path) for comparison of wall time
-python tools/train_ppo_torch.py --env Env01-v1 --envs 16384 --iters 60 --n-steps 64 --epochs 4 --minibatch 8192 --lr 3e-4 --gamma 0.999 --reward-clip 1.0 --eval-steps 1500 --out gpurun_out/ppo_r02/env01_v1_torch_rollout.json > gpurun_out/ppo_r02/torch.log 2>&1
-tail -3 gpurun_out/ppo_r02/torch.log | cut -c1-400
+mkdir -p gpurun_out/r2r
+run() { echo "variant [$1] [$2]" >> gpurun_out/r2r/variants.log; python bench.py --steps 100 --warmup 10 --no-cpu-baseline $2 2>> gpurun_out/r2r/err.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['kernel_ms_min_median_max'])" >> gpurun_out/r2r/variants.log; }
+build() { BRS_EXTRA_HIPCC_FLAGS="$1" python -c "
+from balance_robot_mujoco_rl_amd import _lib
+_lib.build(force=True)" 2>> gpurun_out/r2r/err.log; }
+build "-DBRS_CLASS_V1"; run "-DBRS_CLASS_V1" ""; run "-DBRS_CLASS_V1" ""
+build ""; run "" ""; run "" ""
+cat gpurun_out/r2r/variants.log
+python tools/phase_timing.py > gpurun_out/r2r/phase.log 2>&1; sed -n 12,16p gpurun_out/r2r/phase.log
