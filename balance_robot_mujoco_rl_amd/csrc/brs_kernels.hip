@@ -56,11 +56,10 @@ template <int VARIANT> __device__ __forceinline__ Params<float> fold_params(cons
 }
 
 template <bool BLK, int VARIANT>
-__global__ void __launch_bounds__(256) brs_step_kernel(const Params<float> Prt, const int N, double* __restrict__ d,
-                                                       float* __restrict__ f, int* __restrict__ ii,
-                                                       const float* __restrict__ actions, float* __restrict__ obs,
-                                                       float* __restrict__ reward, uint8_t* __restrict__ terminated,
-                                                       uint8_t* __restrict__ truncated, float* __restrict__ terminal_obs) {
+__device__ __forceinline__ void step_body(const Params<float>& Prt, const int N, double* __restrict__ d, float* __restrict__ f,
+                                          int* __restrict__ ii, const float* __restrict__ actions, float* __restrict__ obs,
+                                          float* __restrict__ reward, uint8_t* __restrict__ terminated,
+                                          uint8_t* __restrict__ truncated, float* __restrict__ terminal_obs) {
   extern __shared__ float brs_lds_dyn[];
   float* lds = brs_lds_dyn;
   const int lane_slot = blockIdx.x * blockDim.x + threadIdx.x;
@@ -118,6 +117,22 @@ __global__ void __launch_bounds__(256) brs_step_kernel(const Params<float> Prt, 
   reward[i] = rew;
   terminated[i] = (uint8_t)te;
   truncated[i] = (uint8_t)tr;
+}
+
+#define BRS_STEP_ARGS                                                                                                      \
+  const Params<float> Prt, const int N, double *__restrict__ d, float *__restrict__ f, int *__restrict__ ii,              \
+      const float *__restrict__ actions, float *__restrict__ obs, float *__restrict__ reward, uint8_t *__restrict__ terminated, \
+      uint8_t *__restrict__ truncated, float *__restrict__ terminal_obs
+template <bool BLK, int VARIANT> __global__ void __launch_bounds__(256) brs_step_kernel(BRS_STEP_ARGS) {
+  step_body<BLK, VARIANT>(Prt, N, d, f, ii, actions, obs, reward, terminated, truncated, terminal_obs);
+}
+// The Env01-family body (8 dofs, 336 registers when left alone) capped at 256 registers so that TWO waves fit a SIMD
+// (LDS: 14 KB per wave, no limit).  Measured, Env01-v2: 65,536 envs (1,024 waves = one per SIMD either way)
+// 49.0 vs 48.0 M env-steps/s -- the 109 spilled VGPRs cost nothing visible; 131,072 / 262,144 / 524,288 envs: 70.9 / 75.5 /
+// 79.1 M vs 49.8 / 50.9 / 51.5 M: the second resident wave is worth x1.42 - 1.54 as soon as a launch has more waves than the
+// chip has SIMDs.  Default for 64-thread workgroups; BRS_ENV01_OCC1=1 selects the uncapped build (A/B).
+template <int VARIANT> __global__ void __launch_bounds__(64, 2) brs_step_kernel_occ2(BRS_STEP_ARGS) {
+  step_body<false, VARIANT>(Prt, N, d, f, ii, actions, obs, reward, terminated, truncated, terminal_obs);
 }
 
 template <bool BLK>
@@ -212,6 +227,7 @@ struct brs_handle {
   int* ii = nullptr;
   size_t nd = 0, nf = 0, ni = 0;
   bool folded = false;       // model constants folded at compile time (default timestep): variant-specific step kernel
+  bool occ2 = false;         // Env01 family: body capped at 256 registers, two waves per SIMD (default; BRS_ENV01_OCC1=1: off)
   bool grouping = false;     // Env03: regroup lanes by cost class after every step (perm / keys live behind the int state)
   int* perm() const { return ii + ni; }                            // [N] lane slot -> env
   uint8_t* keys() const { return (uint8_t*)(ii + ni + (size_t)N); }  // [N] cost class of every env for its next step
@@ -320,6 +336,7 @@ int brs_create(const brs_config* cfg, brs_handle** out) {
     if (hipMemcpy(h->perm(), id.data(), 2 * N * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return bail("brs_create: lane map init failed");
     h->grouping = h->blk && !(cfg->flags & BRS_FLAG_NO_LANE_GROUPING);
     h->folded = !(cfg->timestep > 0 && cfg->timestep != 2e-5) && !std::getenv("BRS_NO_FOLD");
+    h->occ2 = !h->blk && std::getenv("BRS_ENV01_OCC1") == nullptr;
   }
   // dynamic LDS above the 64 KiB default needs the attribute (Env03, 256-thread blocks: 144 KiB)
   size_t lb = lds_bytes(h);
@@ -332,6 +349,9 @@ int brs_create(const brs_config* cfg, brs_handle** out) {
     want((const void*)brs_step_kernel<false, -1>); want((const void*)brs_step_kernel<false, ENV01_V1>);
     want((const void*)brs_step_kernel<false, ENV01_V2>); want((const void*)brs_step_kernel<false, ENV01_V3>);
     want((const void*)brs_step_kernel<false, ENV02_V1>); want((const void*)brs_physics_kernel<false>);
+    want((const void*)brs_step_kernel_occ2<-1>); want((const void*)brs_step_kernel_occ2<ENV01_V1>);
+    want((const void*)brs_step_kernel_occ2<ENV01_V2>); want((const void*)brs_step_kernel_occ2<ENV01_V3>);
+    want((const void*)brs_step_kernel_occ2<ENV02_V1>);
   }
   if (ea != hipSuccess) return bail(std::string("brs_create: hipFuncSetAttribute: ") + hipGetErrorString(ea));
   *out = h;
@@ -375,6 +395,18 @@ int brs_step(brs_handle* h, const float* actions_dev, float* obs_dev, float* rew
 #define BRS_LAUNCH_STEP(BLK_, VAR_)                                                                                          \
   hipLaunchKernelGGL((brs_step_kernel<BLK_, VAR_>), grid, block, lb, s, h->P, h->N, h->d, h->f, h->ii, actions_dev, obs_dev, \
                      reward_dev, terminated_dev, truncated_dev, terminal_obs_dev)
+#define BRS_LAUNCH_OCC2(VAR_)                                                                                              \
+  hipLaunchKernelGGL((brs_step_kernel_occ2<VAR_>), grid, block, lb, s, h->P, h->N, h->d, h->f, h->ii, actions_dev, obs_dev, \
+                     reward_dev, terminated_dev, truncated_dev, terminal_obs_dev)
+  if (!h->blk && h->occ2 && h->bt == 64) {
+    switch (h->folded ? h->P.variant : -1) {
+      case ENV01_V1: BRS_LAUNCH_OCC2(ENV01_V1); break;
+      case ENV01_V2: BRS_LAUNCH_OCC2(ENV01_V2); break;
+      case ENV01_V3: BRS_LAUNCH_OCC2(ENV01_V3); break;
+      case ENV02_V1: BRS_LAUNCH_OCC2(ENV02_V1); break;
+      default: BRS_LAUNCH_OCC2(-1);
+    }
+  } else
   switch (h->folded ? h->P.variant : -1) {
     case ENV01_V1: BRS_LAUNCH_STEP(false, ENV01_V1); break;
     case ENV01_V2: BRS_LAUNCH_STEP(false, ENV01_V2); break;
@@ -386,6 +418,7 @@ int brs_step(brs_handle* h, const float* actions_dev, float* obs_dev, float* rew
       if (h->blk) BRS_LAUNCH_STEP(true, -1); else BRS_LAUNCH_STEP(false, -1);
   }
 #undef BRS_LAUNCH_STEP
+#undef BRS_LAUNCH_OCC2
   if (h->grouping) hipLaunchKernelGGL(brs_group_kernel, dim3(1), dim3(1024), 0, s, h->N, h->keys(), h->perm());  // lanes of the NEXT step
   BRS_HIP_TRY(h, hipGetLastError());
   return BRS_OK;
