@@ -166,32 +166,48 @@ __global__ void __launch_bounds__(256) brs_physics_kernel(const Params<float> P,
   physics_mem<float, BLK, float>(P, st, d, f, ii, (size_t)N, (size_t)i, ctrl[2 * (size_t)i], ctrl[2 * (size_t)i + 1], nsub);
 }
 
-// stable counting sort of the envs by cost class (4 classes) -> perm[lane slot] = env.  ONE workgroup of 1024 threads: thread t
-// owns the contiguous chunk [t * per, (t + 1) * per) of envs; LDS holds the per-(class, thread) counts, scanned class-major.
+// stable counting sort of the envs by cost class -> perm[lane slot] = env.  ONE workgroup of 1024 threads: thread t owns the
+// contiguous chunk [t * per, (t + 1) * per) of envs; LDS holds the per-(bucket, thread) counts, scanned bucket-major.
 // 65,536 keys = 64 per thread: a few microseconds, once per env step.
-__global__ void __launch_bounds__(1024) brs_group_kernel(const int N, const uint8_t* __restrict__ keys, int* __restrict__ perm) {
-  __shared__ int cnt[4 * 1024];
-  const int t = threadIdx.x, per = (N + 1023) / 1024, lo = t * per, hi = min(N, lo + per);
-  int c[4] = {0, 0, 0, 0};
-  // bucket order along the lanes: floor class, plain, wheel class, both -- the boundary waves then mix (floor | plain) and
-  // (plain | wheel), i.e. cost no more than a pure rare-class wave; (floor | wheel) side by side would pay for both paths
-#if defined(BRS_CLASS_V1)
-#define BRS_BUCKET(k_) (k_)
+// Bucket order along the lanes (keys: brs_state.hpp cost_class):
+//     floor | far A | near (plain) | far B | wheel | floor + wheel
+// A wave pays for every path one of its lanes walks, and the slowest wave ends the launch.  Measured with four buckets:
+// the pure rare-class waves were fine (floor 0.70x, wheel 0.9x, both 1.09x the plain wave) -- the two slowest waves of the
+// launch (1.19x) were the BOUNDARY waves where plain lanes with a full block<->robot patch sat next to rare-class lanes.
+// "far" lanes (no block<->robot work at all; split by env parity into A and B) are put between the classes: a boundary wave
+// then pays one expensive path, not two.
+constexpr int NBUCKET = 6;
+__device__ __forceinline__ int bucket_of(int key, int e) {
+#if defined(BRS_CLASS_V2)
+  const int k = key & 3;
+  return k == 0 ? 2 : (k == 1 ? 0 : (k == 2 ? 4 : 5));
 #else
-#define BRS_BUCKET(k_) ((k_) == 0 ? 1 : ((k_) == 1 ? 0 : (k_)))
+  const int k = key & 3;
+  if (k == 1) return 0;
+  if (k == 2) return 4;
+  if (k == 3) return 5;
+  return (key & 4) ? ((e & 1) ? 3 : 1) : 2;
 #endif
+}
+__global__ void __launch_bounds__(1024) brs_group_kernel(const int N, const uint8_t* __restrict__ keys, int* __restrict__ perm) {
+  __shared__ int cnt[NBUCKET * 1024];
+  __shared__ int part[1024];
+  const int t = threadIdx.x, per = (N + 1023) / 1024, lo = t * per, hi = min(N, lo + per);
+  int c[NBUCKET];
+#pragma unroll
+  for (int k = 0; k < NBUCKET; k++) c[k] = 0;
   for (int e = lo; e < hi; e++) {
-    const int k = BRS_BUCKET(keys[e] & 3);
-    c[0] += k == 0; c[1] += k == 1; c[2] += k == 2; c[3] += k == 3;
+    const int b = bucket_of(keys[e], e);
+#pragma unroll
+    for (int k = 0; k < NBUCKET; k++) c[k] += b == k;
   }
 #pragma unroll
-  for (int k = 0; k < 4; k++) cnt[k * 1024 + t] = c[k];
+  for (int k = 0; k < NBUCKET; k++) cnt[k * 1024 + t] = c[k];
   __syncthreads();
-  // exclusive scan of the 4096 counts (class-major): Hillis-Steele over 4 values per thread
-  int v[4], sum = 0;
+  // exclusive scan of the NBUCKET * 1024 counts (bucket-major): NBUCKET values per thread + Hillis-Steele over the threads
+  int v[NBUCKET], sum = 0;
 #pragma unroll
-  for (int k = 0; k < 4; k++) { v[k] = cnt[4 * t + k]; sum += v[k]; }
-  __shared__ int part[1024];
+  for (int k = 0; k < NBUCKET; k++) { v[k] = cnt[NBUCKET * t + k]; sum += v[k]; }
   part[t] = sum;
   __syncthreads();
   for (int off = 1; off < 1024; off <<= 1) {
@@ -202,14 +218,16 @@ __global__ void __launch_bounds__(1024) brs_group_kernel(const int N, const uint
   }
   int run = part[t] - sum;
 #pragma unroll
-  for (int k = 0; k < 4; k++) { const int x = v[k]; cnt[4 * t + k] = run; run += x; }
+  for (int k = 0; k < NBUCKET; k++) { const int x = v[k]; cnt[NBUCKET * t + k] = run; run += x; }
   __syncthreads();
-  int pos[4];
+  int pos[NBUCKET];
 #pragma unroll
-  for (int k = 0; k < 4; k++) pos[k] = cnt[k * 1024 + t];
+  for (int k = 0; k < NBUCKET; k++) pos[k] = cnt[k * 1024 + t];
   for (int e = lo; e < hi; e++) {
-    const int k = BRS_BUCKET(keys[e] & 3);
-    const int p = k == 0 ? pos[0]++ : (k == 1 ? pos[1]++ : (k == 2 ? pos[2]++ : pos[3]++));
+    const int b = bucket_of(keys[e], e);
+    int p = 0;
+#pragma unroll
+    for (int k = 0; k < NBUCKET; k++) { p = b == k ? pos[k] : p; pos[k] += b == k; }
     perm[p] = e;
   }
 }

@@ -113,6 +113,7 @@ BRS_HD void store_state(const EnvState<R, BLK>& S, double* d, FT* f, int* ii, si
 // Cost class of an env for its NEXT step (Env03): which of the rare, expensive collision paths it is likely to walk.
 //   bit 0: the block can reach the floor within one env step          (plane<->box path + block<->floor rows in the solver)
 //   bit 1: the block can reach a wheel within one env step            (box<->cylinder closest-feature path)
+//   bit 2: the block cannot even reach the torso box                  (no block<->robot work at all: a cheap lane)
 // A wave pays for a path whenever ONE of its 64 lanes walks it, and with one wave per SIMD a launch lasts as long as its
 // slowest wave: brs_step therefore groups envs of one class into the same waves (a permutation env <-> lane, recomputed
 // after every step from these keys).  Purely a scheduling hint: an env's arithmetic does not depend on its lane, a wrong
@@ -141,6 +142,10 @@ template <typename R, bool BLK> BRS_HD int cost_class(const Params<R>& P, const 
     const R dz = dl[2] - P.wheel_pz, dxl = dl[0] + P.wheel_px, dxr = dl[0] - P.wheel_px;
     const R base = dl[1] * dl[1] + dz * dz;
     key |= (base + dxl * dxl < rr * rr || base + dxr * dxr < rr * rr) ? 2 : 0;
+    // bit 2: the block cannot reach the torso box either (no block<->robot path at all this step): such lanes are cheap and
+    // serve as SEPARATORS between the classes along the lane axis (brs_kernels.hip: brs_group_kernel)
+    const R dzt = dl[2] - P.torso_cz, rt = P.torso_brad + P.block_brad + P.cc[CC_BLOCK_ROBOT].margin + reach;
+    key |= (dl[0] * dl[0] + dl[1] * dl[1] + dzt * dzt > rt * rt) ? 4 : 0;
     return key;
   }
 }
