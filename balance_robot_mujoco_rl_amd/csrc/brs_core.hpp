@@ -1216,6 +1216,7 @@ template <typename R, bool BLK> struct Sim {
         t2[k] = v2_fma(sWn2, gn[k], v2_mul(sW22, g2[k]));
         rhs2[P0 + k] = v2_fma(srn, gn[k], v2_fma(sr1, g1[k], v2_fma(sr2, g2[k], rhs2[P0 + k])));
       }
+#if defined(BRS_H_CHAINED)
 #pragma unroll
       for (int a = 0; a < 2 * NPA; a++) {
         const R ga = (a & 1) ? gn[a / 2].y : gn[a / 2].x, gb = (a & 1) ? g1[a / 2].y : g1[a / 2].x, gc = (a & 1) ? g2[a / 2].y : g2[a / 2].x;
@@ -1224,6 +1225,22 @@ template <typename R, bool BLK> struct Sim {
         for (int k = 0; k <= a / 2; k++)
           H[hp(2 * P0 + a, P0 + k)] = v2_fma(sa, tn[k], v2_fma(sb, t1[k], v2_fma(sc, t2[k], H[hp(2 * P0 + a, P0 + k)])));
       }
+#else
+      // three sweeps over the touched part of H, one frame axis each: a v_pk_fma_f32 feeding the next v_pk_fma_f32 costs a
+      // wait state (s_nop) on gfx950; chained per entry the compiler left 166 of them in the loop, swept per axis the
+      // dependent pair is a whole sweep apart
+#pragma unroll
+      for (int axis = 0; axis < 3; axis++) {
+        const V2<R>* gg = axis == 0 ? g2 : (axis == 1 ? g1 : gn);
+        const V2<R>* tt = axis == 0 ? t2 : (axis == 1 ? t1 : tn);
+#pragma unroll
+        for (int a = 0; a < 2 * NPA; a++) {
+          const V2<R> sg = v2_splat((a & 1) ? gg[a / 2].y : gg[a / 2].x);
+#pragma unroll
+          for (int k = 0; k <= a / 2; k++) H[hp(2 * P0 + a, P0 + k)] = v2_fma(sg, tt[k], H[hp(2 * P0 + a, P0 + k)]);
+        }
+      }
+#endif
       return mk;
     }
 
