@@ -1,11 +1,9 @@
-mkdir -p gpurun_out/final_e
-python -m pytest tests -m gpu -q > gpurun_out/final_e/gpu_tests.log 2>&1; tail -2 gpurun_out/final_e/gpu_tests.log
-bash tools/profile_r02.sh gpurun_out/prof_r02_env03 Env03-v2 > gpurun_out/final_e/prof_env03.log 2>&1
-python - <<'PY'
-import json
-d=json.load(open("gpurun_out/prof_r02_env03/summary.json")); b=d["bench"]
-print("env03", b["value"], b["ms_per_step"], d.get("kernel_trace_ms"), d.get("valu"), d.get("hbm_traffic"))
-PY
-python tools/vecenv_rate.py > gpurun_out/final_e/vecenv_rate.json 2>> gpurun_out/final_e/err.log; cut -c1-330 gpurun_out/final_e/vecenv_rate.json
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/final_e/bench_20_5.json 2>> gpurun_out/final_e/err.log; cut -c1-160 gpurun_out/final_e/bench_20_5.json
-python tools/phase_timing.py > gpurun_out/final_e/phase.log 2>&1; head -16 gpurun_out/final_e/phase.log
+mkdir -p gpurun_out/r2v
+run() { echo "variant [$1]" >> gpurun_out/r2v/variants.log; python bench.py --steps 100 --warmup 10 --no-cpu-baseline 2>> gpurun_out/r2v/err.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['kernel_ms_min_median_max'])" >> gpurun_out/r2v/variants.log; }
+build() { BRS_EXTRA_HIPCC_FLAGS="$1" python -c "
+from balance_robot_mujoco_rl_amd import _lib
+_lib.build(force=True)" 2>> gpurun_out/r2v/err.log; }
+for v in "" "-Xarch_device -fslp-vectorize" "-Xarch_device -mllvm=-amdgpu-schedule-metric-bias=0" "-Xarch_device -mllvm=-amdgpu-use-amdgpu-trackers=1" "-Xarch_device -mllvm=-enable-misched=0" "-Xarch_device -mllvm=-amdgpu-enable-max-ilp-scheduling-strategy=1" "-Xarch_device -O2" ""; do
+  build "$v" && run "$v"
+done
+cat gpurun_out/r2v/variants.log; tail -5 gpurun_out/r2v/err.log | cut -c1-300

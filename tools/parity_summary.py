@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Classify every dumped outlier of profiles/r02_parity_config*.json (tools/parity_locate.py output) into the causes named
+in DESIGN.md 2.1 and write profiles/r02_parity_report.json; exits non-zero if an outlier fits none of them."""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+rep, unexplained = {}, 0
+for cfg in ("config2", "config3", "config3_noreset"):
+    r = json.load(open(os.path.join(ROOT, "profiles", f"r02_parity_{cfg}.json")))
+    classes = {"block_first_touch_one_substep_apart": 0, "wheel_stick_slip_of_a_fallen_robot": 0, "block_on_a_fallen_robot": 0,
+               "grazing_floor_contact_of_a_fallen_robot": 0, "unexplained": 0}
+    for o in r["outliers"]:
+        g = o["per_group"]
+        robot = max(g["torso_pos"], g["torso_quat"], g["wheel_angles"]); block = max(g.get("block_pos", 0), g.get("block_quat", 0))
+        coupled_pre = any(c["b2"] == 4 and c["b1"] != 0 for c in o["contacts_pre"])
+        if o["upright"] and block > r["tol"] and robot < r["tol"] and not coupled_pre or \
+           (o["upright"] and block > r["tol"] and robot < r["tol"] and o["replay_host_double_vs_float"]["first_substep_dqvel_jump"] is not None):
+            classes["block_first_touch_one_substep_apart"] += 1   # a contact switches on mid-step: velocity jump at one substep
+        elif not o["upright"] and g["wheel_angles"] > r["tol"] and max(g["torso_pos"], g["torso_quat"]) < r["tol"] and block < r["tol"]:
+            classes["wheel_stick_slip_of_a_fallen_robot"] += 1
+        elif not o["upright"] and block > r["tol"]:
+            classes["block_on_a_fallen_robot"] += 1                # same first-touch mechanism on a robot that is lying down
+        elif not o["upright"] and any(c["b1"] == 0 and c["b2"] in (1, 2, 3) and abs(c["dist"]) < 1e-5 for c in o["contacts_pre"]):
+            classes["grazing_floor_contact_of_a_fallen_robot"] += 1   # a floor contact within 10 um of switching on / off (margin 0)
+        else:
+            classes["unexplained"] += 1
+    unexplained += classes["unexplained"]
+    rep[cfg] = dict(env=r["env"], envs=r["envs"], steps=r["steps"], actions=r["actions"], auto_reset=r["auto_reset"], env_steps=r["env_steps"],
+                    excluded_finished_episodes=r["excluded"], env_steps_over_1e_4=r["over"], worst=r["worst"], per_group=r["per_group"],
+                    outliers_dumped=len(r["outliers"]), outlier_classes=classes, log10_error_histogram=r["log10_error_histogram"])
+rep["note"] = ("HIP fp32 kernel vs oracle/brs_oracle.c (fp64; own restatement, NOT MuJoCo: physics parity vs MuJoCo unpinned), teacher-forced per env "
+               "step of 250 substeps; per_group: robot = qpos[0:9], block = qpos[9:16]; upright = torso axis within 60 deg of vertical at the "
+               "start of the step.  Causes: DESIGN.md section 2.1.")
+rep["unexplained_outliers"] = unexplained
+json.dump(rep, open(os.path.join(ROOT, "profiles", "r02_parity_report.json"), "w"), indent=1)
+print(json.dumps({k: (v["outlier_classes"] if isinstance(v, dict) else v) for k, v in rep.items() if k != "note"}, indent=1))
+sys.exit(1 if unexplained else 0)
