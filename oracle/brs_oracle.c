@@ -466,8 +466,13 @@ static void clip_quad_rect(double V[4][3], double a, double b, double margin, do
   for (int i = 0; i < 16; i++) if (valid[i] && !(cand[i][2] < margin)) valid[i] = 0;
 }
 
-int bo_box_box_points(const double* sT, double s, const double* cg, const double* RTB, double margin, double* pos /*[4][3]*/,
-                      double* dist /*[4]*/, double* nrm /*[3]*/, int* code, double* raw /*[16][4] or NULL*/, int* nraw) {
+/* study switch (tests only, never set by the product's checkers): keep ALL clipped points (<= 8, as MuJoCo's mjc_BoxBox
+ * does) instead of the 4 deepest -- used to measure what the kernel's 4-slot patch budget costs in fidelity */
+static int g_boxbox_keep_all = 0;
+void bo_set_boxbox_keep_all(int on) { g_boxbox_keep_all = on; }
+
+int bo_box_box_points(const double* sT, double s, const double* cg, const double* RTB, double margin, double* pos /*[4][3] ([8][3] with keep_all)*/,
+                      double* dist /*[4] ([8])*/, double* nrm /*[3]*/, int* code, double* raw /*[16][4] or NULL*/, int* nraw) {
   *code = -1;
   if (nraw) *nraw = 0;
   /* --- separating axes: 6 faces, 9 edge pairs; keep the axis of LARGEST separation (least penetration) */
@@ -589,7 +594,7 @@ int bo_box_box_points(const double* sT, double s, const double* cg, const double
   }
   if (cnt == 0) return 0;
   *code = axF;
-  if (cnt > 4) { /* reduction: keep the 4 deepest (ties: lower candidate index) */
+  if (cnt > 4 && !g_boxbox_keep_all) { /* reduction: keep the 4 deepest (ties: lower candidate index) */
     int keep[16] = {0};
     for (int pass = 0; pass < 4; pass++) {
       double bd = 1e300; int bi = -1;
@@ -611,7 +616,7 @@ static void box_box(const model_t* m, const double* tpos, const double* tmat, co
   mulMatTVec3(cg, tmat, dw);
   for (int i = 0; i < 3; i++)
     for (int j = 0; j < 3; j++) RTB[3 * i + j] = tmat[i] * bmat[j] + tmat[3 + i] * bmat[3 + j] + tmat[6 + i] * bmat[6 + j];
-  double pos[12], dist[4], nT[3];
+  double pos[24], dist[8], nT[3];
   int code, cnt = bo_box_box_points(m->torso_size, m->block_size[0], cg, RTB, cp->margin, pos, dist, nT, &code, NULL, NULL);
   for (int c = 0; c < cnt; c++) {
     double pw[3], nw[3];

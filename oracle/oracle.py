@@ -80,6 +80,7 @@ def lib():
         L.bo_pitch_yaw.argtypes = [dp, dp, dp]
         ip = C.POINTER(C.c_int)
         L.bo_box_box_points.argtypes = [dp, C.c_double, dp, dp, C.c_double, dp, dp, dp, ip, dp, ip]
+        L.bo_set_boxbox_keep_all.argtypes = [C.c_int]
         L.bo_box_cyl_point.argtypes = [dp, dp, C.c_double, C.c_double, C.c_double, C.c_double, dp, dp, dp]
         L.bo_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.bo_uniform.restype = C.c_double
@@ -112,11 +113,16 @@ def box_box_points(sT, s, cg, RTB, margin):
     """block<->torso generator on its own (torso-geom frame): (points[<=4,3], dists, normal, code, raw[<=16,4])"""
     c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
     sT, cg, RTB = c(sT), c(cg), c(RTB).reshape(9)
-    pos = np.zeros(12); dist = np.zeros(4); nrm = np.zeros(3); raw = np.zeros(64)
+    pos = np.zeros(24); dist = np.zeros(8); nrm = np.zeros(3); raw = np.zeros(64)
     code, nraw = C.c_int(), C.c_int()
     n = lib().bo_box_box_points(_dp(sT), float(s), _dp(cg), _dp(RTB), float(margin), _dp(pos), _dp(dist), _dp(nrm),
                                 C.byref(code), _dp(raw), C.byref(nraw))
-    return pos.reshape(4, 3)[:n].copy(), dist[:n].copy(), nrm, code.value, raw.reshape(16, 4)[:nraw.value].copy()
+    return pos.reshape(8, 3)[:n].copy(), dist[:n].copy(), nrm, code.value, raw.reshape(16, 4)[:nraw.value].copy()
+
+
+def set_boxbox_keep_all(on):
+    """study switch (process-wide): box-box patches keep all <= 8 clipped points, like MuJoCo, instead of the 4 deepest"""
+    lib().bo_set_boxbox_keep_all(int(bool(on)))
 
 
 def box_cyl_point(d, RTB, s, r, hl, margin):
