@@ -512,7 +512,12 @@ int brs_debug_counters(unsigned long long* out16) {
 #endif
 const char* brs_step_kernel_name(const brs_handle* h) {
   if (!h) return "";
-  return h->blk ? "brs_step_kernel<true" : "brs_step_kernel<false";  // (prefix: the variant is a second template argument)
+  // the instantiation brs_step launches, spelled as rocprofv3 prints it
+  static thread_local char name[64];
+  const int var = h->folded ? h->P.variant : -1;
+  if (!h->blk && h->occ2 && h->bt == 64) std::snprintf(name, sizeof name, "brs_step_kernel_occ2<%d>", var);
+  else std::snprintf(name, sizeof name, "brs_step_kernel<%s, %d>", h->blk ? "true" : "false", var);
+  return name;
 }
 
 }  // extern "C"
