@@ -201,14 +201,26 @@ template <typename R> struct Stream {
 };
 
 // ------------------------------------------------------------------------------------ per-lane contact store
-// floor-contact slots hold 7 words, coupled (block<->robot) slots 10 plus 3 shared contact-frame slots of 3 words (frame 0:
-// the torso<->block patch, 1 / 2: the wheel contacts); word k of the lane's column lives at base[k*stride]
-// (GPU: stride 64 = one LDS row per word, consecutive lanes on consecutive banks).  6 coupled slots = 4 patch points + one
-// point per wheel: the generator can never produce more, nothing is dropped.  153 words/lane = 38.25 KiB per wave: 4 waves/CU.
-enum { SLOT_ROBOT = 0, N_ROBOT_SLOTS = 8, SLOT_BLOCK = 8, N_BLOCK_SLOTS = 4, N_COUPLED_SLOTS = 6, SLOT_WORDS = 7,
+// floor-contact slots hold 7 words, coupled (block<->robot) slots 10 plus 2 shared contact-frame slots of 3 words (frame 0:
+// the torso<->block patch, 1: the wheel contact -- the block can touch one wheel at most); word k of the lane's column lives
+// at base[k*stride] (GPU: stride 64 = one LDS row per word, consecutive lanes on consecutive banks).  7 coupled slots =
+// PATCH_MAX = 6 patch points + the wheel point: nothing the generator emits is dropped.  160 words/lane = 40 KiB per wave:
+// exactly 4 waves per 160-KiB CU (measured: no loss against 153 words).
+#ifndef BRS_PATCH_MAX
+#define BRS_PATCH_MAX 6  // (A/B builds may set 4: round-2a behaviour)
+#endif
+enum { PATCH_MAX = BRS_PATCH_MAX };
+#if defined(BRS_TIMING)  // diagnostic build: one robot<->floor slot less makes room for the per-wave timing slots (the bench workload
+enum { BRS_NRS = 7 };    // never has more than 4 robot<->floor contacts)
+#else
+enum { BRS_NRS = 8 };
+#endif
+enum { SLOT_ROBOT = 0, N_ROBOT_SLOTS = BRS_NRS, SLOT_BLOCK = BRS_NRS, N_BLOCK_SLOTS = 4, N_COUPLED_SLOTS = PATCH_MAX + 1, SLOT_WORDS = 7,
        COUPLED_WORDS = 10, COUPLED_BASE = (N_ROBOT_SLOTS + N_BLOCK_SLOTS) * SLOT_WORDS,
-       FRAME_BASE = COUPLED_BASE + N_COUPLED_SLOTS * COUPLED_WORDS, N_FRAME_SLOTS = 3,
-       LDS_WORDS_ENV01 = N_ROBOT_SLOTS * SLOT_WORDS, LDS_WORDS_ENV03 = FRAME_BASE + 3 * N_FRAME_SLOTS };
+       FRAME_BASE = COUPLED_BASE + N_COUPLED_SLOTS * COUPLED_WORDS, N_FRAME_SLOTS = 2,
+       LDS_WORDS_ENV01 = N_ROBOT_SLOTS * SLOT_WORDS,
+       LDS_WORDS_ENV03 = FRAME_BASE + 3 * N_FRAME_SLOTS };
+static_assert(LDS_WORDS_ENV03 <= 160, "4 waves per CU need <= 160 words per lane");
 template <typename R> struct Store {
   R* base;
   int stride;
@@ -220,12 +232,12 @@ template <typename R> struct Store {
   BRS_HD void setf(int f, int w, R v) { base[(FRAME_BASE + 3 * f + w) * stride] = v; }
 };
 // Per-lane bookkeeping of the contact lists lives in registers, not in LDS: 4-bit active-row masks packed 8 slots
-// to a word (R: robot<->floor slots 0..7; B: block<->floor 0..3; C: block<->robot 0..5), body selectors 2 bits per slot.
+// to a word (R: robot<->floor slots 0..7; B: block<->floor 0..3; C: block<->robot 0..6), body selectors 2 bits per slot.
 struct Masks { uint32_t hR, hB, hC, nR, nB, nC; };  // h: the masks H was built with; n: masks at the latest evaluated point
 BRS_HD int get4(uint32_t m, int slot) { return (int)((m >> (4 * slot)) & 15u); }
 BRS_HD uint32_t put4(int v, int slot) { return (uint32_t)v << (4 * slot); }
-// sels word: bits [0,16) robot<->floor body (0 torso, 1 L wheel, 2 R wheel), [16,28) block<->robot body (which is also the
-// contact-frame slot: the torso patch shares frame 0, each wheel contact owns frame 1 / 2)
+// sels word: bits [0,16) robot<->floor body (0 torso, 1 L wheel, 2 R wheel), [16,30) block<->robot body (0: a point of
+// the torso patch, contact frame 0; 1 / 2: the wheel contact, contact frame 1)
 BRS_HD int sel_robot(uint32_t sels, int c) { return (int)((sels >> (2 * c)) & 3u); }
 BRS_HD int sel_coupled(uint32_t sels, int c) { return (int)((sels >> (16 + 2 * c)) & 3u); }
 
@@ -621,7 +633,7 @@ template <typename R, bool BLK> struct Sim {
     st.setc(k, 7, -c.B * c.mu * vt1);
     st.setc(k, 8, -c.B * c.mu * vt2);
     st.setc(k, 9, imp * rcp_((1 - imp) * cD));
-    if (!share) { st.setf(sel, 0, fw[0]); st.setf(sel, 1, fw[1]); st.setf(sel, 2, fw[2]); }
+    if (!share) { const int fs = sel ? 1 : 0; st.setf(fs, 0, fw[0]); st.setf(fs, 1, fw[1]); st.setf(fs, 2, fw[2]); }
     F.sels |= (uint32_t)sel << (16 + 2 * k);
     F.nc++;
   }
@@ -648,7 +660,7 @@ template <typename R, bool BLK> struct Sim {
     R s = P.block_s;
     BRS_TIC(10);
     // (i) torso box <-> block box: the standard clipped-polygon box-box (15-axis SAT; face case: the incident face clipped
-    // against the reference rectangle, <= 8 points, the 4 deepest kept; edge case: one point between the closest points of
+    // against the reference rectangle, <= 8 points, the 6 deepest kept; edge case: one point between the closest points of
     // the two edges).  Same specification as oracle/brs_oracle.c bo_box_box_points (axis choice, candidate order,
     // reduction); MuJoCo's mjc_BoxBox point sets are UNPINNED.  No runtime-indexed register arrays: the <= 16 clip
     // candidates are parked in the lane's LDS column (robot<->floor slot region, not yet written in this substep) and
@@ -848,9 +860,9 @@ template <typename R, bool BLK> struct Sim {
             }
           }
           BRS_MARK("cc_reduce");
-          // keep the 4 deepest (ties: lower candidate index).  tau = 4th smallest valid g from a pruned sorting network
-          // (sorted groups of 4, bitonic half-merges keeping the low half) -- branch-free: some lane of a wave needs it on
-          // most trips, and a per-lane selection loop would cost every lane its worst case
+          // keep the PATCH_MAX = 6 deepest (ties: lower candidate index).  tau = 6th smallest valid g from a sorting network
+          // (sorted groups of 4, bitonic merges to two sorted octets, low half of their merge) -- branch-free: some lane of
+          // a wave needs it on most trips, and a per-lane selection loop would cost every lane its worst case
           uint32_t keep = vmask;
           {
             R k_[16];
@@ -861,16 +873,23 @@ template <typename R, bool BLK> struct Sim {
             for (int g4 = 0; g4 < 16; g4 += 4) {
               BRS_CSWAP(g4 + 0, g4 + 1); BRS_CSWAP(g4 + 2, g4 + 3); BRS_CSWAP(g4 + 0, g4 + 2); BRS_CSWAP(g4 + 1, g4 + 3); BRS_CSWAP(g4 + 1, g4 + 2);
             }
-            // merge (0..3, 4..7) -> 0..3 ; (8..11, 12..15) -> 8..11 ; then (0..3, 8..11) -> 0..3  (low halves, re-sorted)
 #pragma unroll
-            for (int m = 0; m < 3; m++) {
-              const int A = m == 1 ? 8 : 0, B = m == 0 ? 4 : (m == 1 ? 12 : 8);
+            for (int o8 = 0; o8 < 16; o8 += 8) {  // two sorted quartets -> one sorted octet
+              BRS_CSWAP(o8 + 0, o8 + 7); BRS_CSWAP(o8 + 1, o8 + 6); BRS_CSWAP(o8 + 2, o8 + 5); BRS_CSWAP(o8 + 3, o8 + 4);
 #pragma unroll
-              for (int q = 0; q < 4; q++) k_[A + q] = min_(k_[A + q], k_[B + 3 - q]);
-              BRS_CSWAP(A + 0, A + 2); BRS_CSWAP(A + 1, A + 3); BRS_CSWAP(A + 0, A + 1); BRS_CSWAP(A + 2, A + 3);
+              for (int h4 = 0; h4 < 8; h4 += 4) {
+                BRS_CSWAP(o8 + h4 + 0, o8 + h4 + 2); BRS_CSWAP(o8 + h4 + 1, o8 + h4 + 3); BRS_CSWAP(o8 + h4 + 0, o8 + h4 + 1); BRS_CSWAP(o8 + h4 + 2, o8 + h4 + 3);
+              }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) k_[q] = min_(k_[q], k_[15 - q]);  // the 8 smallest of all (bitonic)
+            BRS_CSWAP(0, 4); BRS_CSWAP(1, 5); BRS_CSWAP(2, 6); BRS_CSWAP(3, 7);
+#pragma unroll
+            for (int h4 = 0; h4 < 8; h4 += 4) {
+              BRS_CSWAP(h4 + 0, h4 + 2); BRS_CSWAP(h4 + 1, h4 + 3); BRS_CSWAP(h4 + 0, h4 + 1); BRS_CSWAP(h4 + 2, h4 + 3);
             }
 #undef BRS_CSWAP
-            const R tau = k_[3];
+            const R tau = k_[PATCH_MAX - 1];
             uint32_t lt = 0, eq = 0;
 #pragma unroll
             for (int q = 0; q < 16; q++) {
@@ -878,16 +897,16 @@ template <typename R, bool BLK> struct Sim {
               lt |= (vq & (gq[q] < tau)) ? (1u << q) : 0u;
               eq |= (vq & (gq[q] == tau)) ? (1u << q) : 0u;
             }
-            int need = 4 - (int)__builtin_popcount(lt);
+            int need = PATCH_MAX - (int)__builtin_popcount(lt);
             uint32_t kp = lt;
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
+            for (int t = 0; t < PATCH_MAX; t++) {
               const bool go = (t < need) & (eq != 0u);
               const uint32_t lowbit = eq & (0u - eq);
               kp |= go ? lowbit : 0u;
               eq &= go ? ~lowbit : ~0u;
             }
-            keep = __builtin_popcount(vmask) > 4 ? kp : vmask;
+            keep = __builtin_popcount(vmask) > PATCH_MAX ? kp : vmask;
           }
           BRS_MARK("cc_scatter");
           const int nkeep = (int)__builtin_popcount(keep);
@@ -898,7 +917,7 @@ template <typename R, bool BLK> struct Sim {
           for (int q = 0; q < 16; q++) {
             const bool kq = ((keep >> q) & 1u) != 0;
             const int rank = (int)__builtin_popcount(keep & ((1u << q) - 1u));
-            R* dst = scr + (3 * (kq ? rank : 4)) * st.stride;
+            R* dst = scr + (3 * (kq ? rank : PATCH_MAX)) * st.stride;
             dst[0] = cu_[q]; dst[st.stride] = cv_[q]; dst[2 * st.stride] = gq[q];
           }
           BRS_MARK("cc_insert");
@@ -1040,7 +1059,8 @@ template <typename R, bool BLK> struct Sim {
     C.sel = sel_coupled(F.sels, c);
     C.mu = P.cc[CC_BLOCK_ROBOT].mu;
     if (c == 0 || C.sel != prev_sel) {  // a new patch: its frame (the torso patch is contiguous, a wheel contact is alone)
-      R fw[9] = {st.getf(C.sel, 0), st.getf(C.sel, 1), st.getf(C.sel, 2), 0, 0, 0, 0, 0, 0};
+      const int fs = C.sel ? 1 : 0;
+      R fw[9] = {st.getf(fs, 0), st.getf(fs, 1), st.getf(fs, 2), 0, 0, 0, 0, 0, 0};
       make_frame(fw);
 #pragma unroll
       for (int k = 0; k < 3; k++) { mulT_(F.RT, fw + 3 * k, C.dT[k]); mulT_(F.RB, fw + 3 * k, C.dB[k]); }

@@ -413,10 +413,10 @@ static void plane_box(const model_t* m, const double* bpos, const double* bmat, 
  * without the source, so this is the STANDARD clipped-polygon box-box (Gottschalk OBB SAT + Sutherland-Hodgman /
  * Liang-Barsky clipping as in ODE's dBoxBox) and a closest-feature box <-> capped-cylinder test, written from their
  * published descriptions.  PARITY WITH MUJOCO'S POINT SETS IS UNPINNED.  The HIP kernel (brs_core.hpp: collide_coupled)
- * follows the same specification: same axis choice, same candidate enumeration order, same reduction to 4 points.
+ * follows the same specification: same axis choice, same candidate enumeration order, same reduction to 6 points.
  *
  * box_box_points works in the frame of box T (half sizes sT), box B is a cube of half size s centred at cg with axes =
- * columns of RTB.  Output: <= 4 contact points (T frame), their signed distances, the common normal T -> B.
+ * columns of RTB.  Output: <= 6 contact points (T frame), their signed distances, the common normal T -> B.
  * code: 0..2 T face, 3..5 B face, 6 + 3 i + j edge(T axis i) x edge(B axis j), -1 no contact.
  * raw (optional): every valid candidate BEFORE the reduction to 4, as (x, y, z, dist) in the T frame.
  * ------------------------------------------------------------------------------------------------------------- */
@@ -468,8 +468,9 @@ static void clip_quad_rect(double V[4][3], double a, double b, double margin, do
 
 /* study switch (tests only, never set by the product's checkers): keep ALL clipped points (<= 8, as MuJoCo's mjc_BoxBox
  * does) instead of the 4 deepest -- used to measure what the kernel's 4-slot patch budget costs in fidelity */
-static int g_boxbox_keep_all = 0;
-void bo_set_boxbox_keep_all(int on) { g_boxbox_keep_all = on; }
+static int g_boxbox_max = 6; /* the specification: the kernel's patch budget */
+void bo_set_boxbox_keep_all(int on) { g_boxbox_max = on ? 8 : 6; }
+void bo_set_boxbox_max(int n) { g_boxbox_max = n < 1 ? 1 : (n > 8 ? 8 : n); } /* study switch: keep the n deepest */
 
 int bo_box_box_points(const double* sT, double s, const double* cg, const double* RTB, double margin, double* pos /*[4][3] ([8][3] with keep_all)*/,
                       double* dist /*[4] ([8])*/, double* nrm /*[3]*/, int* code, double* raw /*[16][4] or NULL*/, int* nraw) {
@@ -594,9 +595,9 @@ int bo_box_box_points(const double* sT, double s, const double* cg, const double
   }
   if (cnt == 0) return 0;
   *code = axF;
-  if (cnt > 4 && !g_boxbox_keep_all) { /* reduction: keep the 4 deepest (ties: lower candidate index) */
+  if (cnt > g_boxbox_max) { /* reduction: keep the deepest (ties: lower candidate index) */
     int keep[16] = {0};
-    for (int pass = 0; pass < 4; pass++) {
+    for (int pass = 0; pass < g_boxbox_max; pass++) {
       double bd = 1e300; int bi = -1;
       for (int c = 0; c < 16; c++) if (valid[c] && !keep[c] && cand[c][2] < bd) { bd = cand[c][2]; bi = c; }
       keep[bi] = 1;

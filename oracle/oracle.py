@@ -81,6 +81,7 @@ def lib():
         ip = C.POINTER(C.c_int)
         L.bo_box_box_points.argtypes = [dp, C.c_double, dp, dp, C.c_double, dp, dp, dp, ip, dp, ip]
         L.bo_set_boxbox_keep_all.argtypes = [C.c_int]
+        L.bo_set_boxbox_max.argtypes = [C.c_int]
         L.bo_box_cyl_point.argtypes = [dp, dp, C.c_double, C.c_double, C.c_double, C.c_double, dp, dp, dp]
         L.bo_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.bo_uniform.restype = C.c_double
@@ -123,6 +124,11 @@ def box_box_points(sT, s, cg, RTB, margin):
 def set_boxbox_keep_all(on):
     """study switch (process-wide): box-box patches keep all <= 8 clipped points, like MuJoCo, instead of the 4 deepest"""
     lib().bo_set_boxbox_keep_all(int(bool(on)))
+
+
+def set_boxbox_max(n):
+    """study switch (process-wide): box-box patches keep the n deepest clipped points (4 = the specification, 8 = all)"""
+    lib().bo_set_boxbox_max(int(n))
 
 
 def box_cyl_point(d, RTB, s, r, hl, margin):

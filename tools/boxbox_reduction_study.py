@@ -10,6 +10,7 @@ sys.path.insert(0, ROOT)
 from oracle import oracle as O
 
 ap = argparse.ArgumentParser(); ap.add_argument("--envs", type=int, default=512); ap.add_argument("--steps", type=int, default=200)
+ap.add_argument("--keep", type=int, default=4, help="points the reduced side keeps (4 = the specification)")
 ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_boxbox_reduction_study.json"))
 a = ap.parse_args()
 n, thr = a.envs, min(os.cpu_count() or 1, 64)
@@ -22,14 +23,14 @@ for t in range(a.steps):
     qpos, qvel, warm, tm = A.get_state()
     B.set_state(qpos, qvel, warm, tm); B.set_aux(A.get_aux()); B.set_xpose(*A.get_xpose())
     act = rng.uniform(-1, 1, size=(n, 2)).astype(np.float32)
-    O.set_boxbox_keep_all(False); oa = A.step(act)
-    O.set_boxbox_keep_all(True); ob = B.step(act)
-    O.set_boxbox_keep_all(False)
+    O.set_boxbox_max(a.keep); oa = A.step(act)
+    O.set_boxbox_max(8); ob = B.step(act)
+    O.set_boxbox_max(4)
     skip = oa[2] | oa[3] | ob[2] | ob[3] | (np.isnan(A.get_aux()[:, 1]) != np.isnan(B.get_aux()[:, 1]))
     d = np.abs(A.get_state()[0] - B.get_state()[0])[~skip]
     errs.append(np.stack([d[:, :9].max(axis=1), d[:, 9:].max(axis=1)], 1))
 e = np.concatenate(errs)
-rep = dict(env_steps=int(e.shape[0]), affected_env_steps=int((e.max(axis=1) > 1e-9).sum()),
+rep = dict(kept_points=a.keep, env_steps=int(e.shape[0]), affected_env_steps=int((e.max(axis=1) > 1e-9).sum()),
            robot_qpos=dict(max=float(e[:, 0].max()), p999=float(np.quantile(e[:, 0], 0.999)), over_1e_4=int((e[:, 0] > 1e-4).sum())),
            block_qpos=dict(max=float(e[:, 1].max()), p999=float(np.quantile(e[:, 1], 0.999)), over_1e_4=int((e[:, 1] > 1e-4).sum())),
            note="difference between keeping the 4 deepest and all <= 8 clipped box-box points, oracle vs oracle, teacher-forced per env step")
