@@ -70,7 +70,7 @@ namespace brs {
 
 #if defined(BRS_STATS) && !defined(__HIP_DEVICE_COMPILE__)
 struct Stats { long substeps, solves[3], iters[3], passA[3], backtracks[3]; int last_iters[3]; long hist[17], trips;
-               long cp_calls, cp_reach, cp_torso, cp_wheel, cp_nc, cp_tight_torso, cp_tight_wheel, nfr_hist[9], nfb_hist[5], nc_hist[5]; };
+               long cp_calls, cp_reach, cp_torso, cp_wheel, cp_nc, cp_tight_torso, cp_tight_wheel, nfr_hist[9], nfb_hist[5], nc_hist[8]; };
 inline Stats& stats() { static thread_local Stats s{}; return s; }
 #define BRS_STAT(expr) do { expr; } while (0)
 #else
@@ -236,10 +236,10 @@ template <typename R> struct Store {
 struct Masks { uint32_t hR, hB, hC, nR, nB, nC; };  // h: the masks H was built with; n: masks at the latest evaluated point
 BRS_HD int get4(uint32_t m, int slot) { return (int)((m >> (4 * slot)) & 15u); }
 BRS_HD uint32_t put4(int v, int slot) { return (uint32_t)v << (4 * slot); }
-// sels word: bits [0,16) robot<->floor body (0 torso, 1 L wheel, 2 R wheel), [16,30) block<->robot body (0: a point of
-// the torso patch, contact frame 0; 1 / 2: the wheel contact, contact frame 1)
+// sels word: bits [0,16) robot<->floor body (0 torso, 1 L wheel, 2 R wheel), [16,18) the wheel of the block<->wheel contact (0 none, 1 L,
+// 2 R).  Block<->robot slots 0 .. PATCH_MAX-1 hold the torso patch (contact frame 0), slot PATCH_MAX the wheel contact (frame 1)
 BRS_HD int sel_robot(uint32_t sels, int c) { return (int)((sels >> (2 * c)) & 3u); }
-BRS_HD int sel_coupled(uint32_t sels, int c) { return (int)((sels >> (16 + 2 * c)) & 3u); }
+BRS_HD int sel_wheel_contact(uint32_t sels) { return (int)((sels >> 16) & 3u); }  // 0: no block<->wheel contact, 1 L, 2 R
 
 // ------------------------------------------------------------------------------------ env state (registers)
 template <typename R, bool BLK> struct EnvState {
@@ -607,7 +607,7 @@ template <typename R, bool BLK> struct Sim {
   // fw = world contact frame (normal + MuJoCo's mju_makeFrame tangents), built once per patch by the caller.
   static BRS_HD void add_coupled(const Params<R>& P, Store<R>& st, Frame& F, const ES& S, const R* rT, const R* fw, R dist,
                                  int sel, bool share) {
-    if (F.nc >= N_COUPLED_SLOTS) return;
+    if (sel == 0 && F.nc >= PATCH_MAX) return;
     const ContactClass<R>& c = P.cc[CC_BLOCK_ROBOT];
     R pw[3], rB[3], wc[3], t[3];
     mul_(F.RT, rT, pw);
@@ -626,7 +626,7 @@ template <typename R, bool BLK> struct Sim {
     R vn = dot_(fw, rel), vt1 = dot_(fw + 3, rel), vt2 = dot_(fw + 6, rel);
     R imp = impedance_(c, dist);
     R cD = sel == 0 ? c.cD : P.cD_block_wheel;
-    int k = F.nc;
+    const int k = sel == 0 ? F.nc : PATCH_MAX;  // the wheel contact has its own slot: the patch loops never meet it
     st.setc(k, 0, rT[0]); st.setc(k, 1, rT[1]); st.setc(k, 2, rT[2]);
     st.setc(k, 3, rB[0]); st.setc(k, 4, rB[1]); st.setc(k, 5, rB[2]);
     st.setc(k, 6, -c.B * vn - c.K * imp * (dist - c.margin));
@@ -634,8 +634,8 @@ template <typename R, bool BLK> struct Sim {
     st.setc(k, 8, -c.B * c.mu * vt2);
     st.setc(k, 9, imp * rcp_((1 - imp) * cD));
     if (!share) { const int fs = sel ? 1 : 0; st.setf(fs, 0, fw[0]); st.setf(fs, 1, fw[1]); st.setf(fs, 2, fw[2]); }
-    F.sels |= (uint32_t)sel << (16 + 2 * k);
-    F.nc++;
+    F.sels |= (uint32_t)sel << 16;
+    F.nc += sel == 0 ? 1 : 0;
   }
   static BRS_HD void world_frame(const Frame& F, const R* nTf, R* fw) {  // unit normal in the torso frame -> world contact frame
     mul_(F.RT, nTf, fw);
@@ -1049,23 +1049,24 @@ template <typename R, bool BLK> struct Sim {
     R An, Bt1, Bt2, D, mu;
     int sel;
   };
-  // C persists across the contacts of one pass: a contact of the same patch (same body selector as its predecessor) reuses
-  // the frame rows already rotated into both body frames
-  static BRS_HD void coupled_load(const Params<R>& P, const Store<R>& st, const Frame& F, int c, Coupled& C) {
+  // C persists across the points of the patch: the frame rows rotated into both body frames are computed at its first point.
+  // WHEEL = false: point c of the torso patch (no wheel dof involved); WHEEL = true: the wheel contact (slot PATCH_MAX).
+  template <bool WHEEL> static BRS_HD void coupled_load(const Params<R>& P, const Store<R>& st, const Frame& F, int c, Coupled& C) {
+    const int slot = WHEEL ? (int)PATCH_MAX : c;
 #pragma unroll
-    for (int j = 0; j < 3; j++) { C.rT[j] = st.getc(c, j); C.rB[j] = st.getc(c, 3 + j); }
-    C.An = st.getc(c, 6); C.Bt1 = st.getc(c, 7); C.Bt2 = st.getc(c, 8); C.D = st.getc(c, 9);
-    const int prev_sel = C.sel;
-    C.sel = sel_coupled(F.sels, c);
+    for (int j = 0; j < 3; j++) { C.rT[j] = st.getc(slot, j); C.rB[j] = st.getc(slot, 3 + j); }
+    C.An = st.getc(slot, 6); C.Bt1 = st.getc(slot, 7); C.Bt2 = st.getc(slot, 8); C.D = st.getc(slot, 9);
+    C.sel = WHEEL ? sel_wheel_contact(F.sels) : 0;
     C.mu = P.cc[CC_BLOCK_ROBOT].mu;
-    if (c == 0 || C.sel != prev_sel) {  // a new patch: its frame (the torso patch is contiguous, a wheel contact is alone)
-      const int fs = C.sel ? 1 : 0;
+    if (WHEEL || c == 0) {
+      const int fs = WHEEL ? 1 : 0;
       R fw[9] = {st.getf(fs, 0), st.getf(fs, 1), st.getf(fs, 2), 0, 0, 0, 0, 0, 0};
       make_frame(fw);
 #pragma unroll
       for (int k = 0; k < 3; k++) { mulT_(F.RT, fw + 3 * k, C.dT[k]); mulT_(F.RB, fw + 3 * k, C.dB[k]); }
     }
-    wheel_col(P, C.sel, C.rT, C.wc);
+    if constexpr (WHEEL) wheel_col(P, C.sel, C.rT, C.wc);
+    else { C.wc[0] = 0; C.wc[1] = 0; C.wc[2] = 0; }
   }
 
   // ---- Newton solver of the convex acceleration problem  min 1/2 (x-a0)^T M (x-a0) + sum 1/2 D min(0, J x - aref)^2
@@ -1106,6 +1107,46 @@ template <typename R, bool BLK> struct Sim {
           sm = false;
       }
       return mk;
+    }
+
+    // rows of one block<->robot contact at x (and its force when FORCES): a point of the torso patch or the wheel contact
+    template <bool FORCES, bool WHEEL>
+    static BRS_HD void passA_coupled(const Params<R>& P, Store<R>& st, const Frame& F, Masks& M, const R* x, int c, Coupled& C, R& cst,
+                                     R* l, R* fcon, bool& sm) {
+      coupled_load<WHEEL>(P, st, F, c, C);
+      R t[3];
+      cross_(x + 3, C.rT, t);
+      R paT[3] = {x[0] + t[0], x[1] + t[1], x[2] + t[2]};
+      if constexpr (WHEEL) {
+        const R x6 = x[6], x7 = x[7];
+        const R xs = by_wheel<R>(C.sel, x6, x7);
+        paT[0] += xs * C.wc[0]; paT[1] += xs * C.wc[1]; paT[2] += xs * C.wc[2];
+      }
+      cross_(x + 11, C.rB, t);
+      R paB[3] = {x[8] + t[0], x[9] + t[1], x[10] + t[2]};
+      int mk = rows_(dot_(C.dB[0], paB) - dot_(C.dT[0], paT) - C.An, C.mu * (dot_(C.dB[1], paB) - dot_(C.dT[1], paT)) - C.Bt1,
+                     C.mu * (dot_(C.dB[2], paB) - dot_(C.dT[2], paT)) - C.Bt2, C.D, cst, l, get4(M.hC, c), sm);
+      M.nC |= put4(mk, c);
+      if constexpr (FORCES) {
+        R fn = C.D * (l[0] + l[1] + l[2] + l[3]), f1 = C.D * C.mu * (l[0] - l[1]), f2 = C.D * C.mu * (l[2] - l[3]);
+        R fT[3], fB[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          fT[j] = -(C.dT[0][j] * fn + C.dT[1][j] * f1 + C.dT[2][j] * f2);
+          fB[j] = C.dB[0][j] * fn + C.dB[1][j] * f1 + C.dB[2][j] * f2;
+        }
+        cross_(C.rT, fT, t);
+        fcon[0] += fT[0]; fcon[1] += fT[1]; fcon[2] += fT[2];
+        fcon[3] += t[0]; fcon[4] += t[1]; fcon[5] += t[2];
+        if constexpr (WHEEL) {
+          R fw = dot_(C.wc, fT);
+          fcon[6] += C.sel == 1 ? fw : (R)0;
+          fcon[7] += C.sel == 2 ? fw : (R)0;
+        }
+        cross_(C.rB, fB, t);
+        fcon[8] += fB[0]; fcon[9] += fB[1]; fcon[10] += fB[2];
+        fcon[11] += t[0]; fcon[12] += t[1]; fcon[13] += t[2];
+      }
     }
 
     // pass A: active-row masks at x (same = every mask equals the one H was built with) and, when FORCES, also the cost
@@ -1167,38 +1208,8 @@ template <typename R, bool BLK> struct Sim {
           }
         }
         Coupled C;
-        C.sel = -1;
-        for (int c = 0; c < F.nc; c++) {
-          coupled_load(P, st, F, c, C);
-          R t[3];
-          cross_(x + 3, C.rT, t);
-          const R x6 = x[6], x7 = x[7];
-          R xs = by_wheel<R>(C.sel, x6, x7);
-          R paT[3] = {x[0] + t[0] + xs * C.wc[0], x[1] + t[1] + xs * C.wc[1], x[2] + t[2] + xs * C.wc[2]};
-          cross_(x + 11, C.rB, t);
-          R paB[3] = {x[8] + t[0], x[9] + t[1], x[10] + t[2]};
-          int mk = rows_(dot_(C.dB[0], paB) - dot_(C.dT[0], paT) - C.An, C.mu * (dot_(C.dB[1], paB) - dot_(C.dT[1], paT)) - C.Bt1,
-                         C.mu * (dot_(C.dB[2], paB) - dot_(C.dT[2], paT)) - C.Bt2, C.D, cst, l, get4(M.hC, c), sm);
-          M.nC |= put4(mk, c);
-          if constexpr (FORCES) {
-            R fn = C.D * (l[0] + l[1] + l[2] + l[3]), f1 = C.D * C.mu * (l[0] - l[1]), f2 = C.D * C.mu * (l[2] - l[3]);
-            R fT[3], fB[3];
-  #pragma unroll
-            for (int j = 0; j < 3; j++) {
-              fT[j] = -(C.dT[0][j] * fn + C.dT[1][j] * f1 + C.dT[2][j] * f2);
-              fB[j] = C.dB[0][j] * fn + C.dB[1][j] * f1 + C.dB[2][j] * f2;
-            }
-            cross_(C.rT, fT, t);
-            fcon[0] += fT[0]; fcon[1] += fT[1]; fcon[2] += fT[2];
-            fcon[3] += t[0]; fcon[4] += t[1]; fcon[5] += t[2];
-            R fw = dot_(C.wc, fT);
-            fcon[6] += C.sel == 1 ? fw : (R)0;
-            fcon[7] += C.sel == 2 ? fw : (R)0;
-            cross_(C.rB, fB, t);
-            fcon[8] += fB[0]; fcon[9] += fB[1]; fcon[10] += fB[2];
-            fcon[11] += t[0]; fcon[12] += t[1]; fcon[13] += t[2];
-          }
-        }
+        for (int c = 0; c < F.nc; c++) passA_coupled<FORCES, false>(P, st, F, M, x, c, C, cst, l, fcon, sm);
+        if (sel_wheel_contact(F.sels)) passA_coupled<FORCES, true>(P, st, F, M, x, PATCH_MAX, C, cst, l, fcon, sm);
       }
       cost = cst;
       same = sm;
@@ -1209,14 +1220,18 @@ template <typename R, bool BLK> struct Sim {
     // One contact into H and rhs through its 3x3 weight matrix in the contact frame:
     //   rows j_k = G_n +- mu G_t ;  sum_k act_k D j_k j_k^T = G^T W G ,  W = D [[sum a, mu(a0-a1), mu(a2-a3)], [., mu^2(a0+a1), 0], [., 0, mu^2(a2+a3)]]
     // G rows arrive as pairs over the dof range [2*P0, 2*(P0+NPA)); `eval`: decide the active rows at x (else from mnew).
-    template <int P0, int NPA>
+    // SKIP: a pair of the range whose G entries are zero (the wheel dofs for a point of the torso patch): left out everywhere
+    template <int P0, int NPA, int SKIP = -1>
     static BRS_HD int contact_into(V2<R>* H, V2<R>* rhs2, const V2<R>* gn, const V2<R>* g1, const V2<R>* g2, R mu, R D, R An,
                                    R Bt1, R Bt2, bool eval, int mnew, const V2<R>* x2) {
       int mk = mnew;
       if (eval) {
         V2<R> an = v2_splat<R>((R)0), a1 = an, a2 = an;
 #pragma unroll
-        for (int k = 0; k < NPA; k++) { an = v2_fma(gn[k], x2[P0 + k], an); a1 = v2_fma(g1[k], x2[P0 + k], a1); a2 = v2_fma(g2[k], x2[P0 + k], a2); }
+        for (int k = 0; k < NPA; k++) {
+          if (k == SKIP) continue;
+          an = v2_fma(gn[k], x2[P0 + k], an); a1 = v2_fma(g1[k], x2[P0 + k], a1); a2 = v2_fma(g2[k], x2[P0 + k], a2);
+        }
         R cn = (an.x + an.y) - An, c1 = mu * (a1.x + a1.y) - Bt1, c2 = mu * (a2.x + a2.y) - Bt2;
         mk = (cn + c1 < 0 ? 1 : 0) | (cn - c1 < 0 ? 2 : 0) | (cn + c2 < 0 ? 4 : 0) | (cn - c2 < 0 ? 8 : 0);
       }
@@ -1231,21 +1246,12 @@ template <typename R, bool BLK> struct Sim {
       const V2<R> srn = v2_splat(rn), sr1 = v2_splat(r1), sr2 = v2_splat(r2);
 #pragma unroll
       for (int k = 0; k < NPA; k++) {
+        if (k == SKIP) continue;
         tn[k] = v2_fma(sWnn, gn[k], v2_fma(sWn1, g1[k], v2_mul(sWn2, g2[k])));
         t1[k] = v2_fma(sWn1, gn[k], v2_mul(sW11, g1[k]));
         t2[k] = v2_fma(sWn2, gn[k], v2_mul(sW22, g2[k]));
         rhs2[P0 + k] = v2_fma(srn, gn[k], v2_fma(sr1, g1[k], v2_fma(sr2, g2[k], rhs2[P0 + k])));
       }
-#if defined(BRS_H_CHAINED)
-#pragma unroll
-      for (int a = 0; a < 2 * NPA; a++) {
-        const R ga = (a & 1) ? gn[a / 2].y : gn[a / 2].x, gb = (a & 1) ? g1[a / 2].y : g1[a / 2].x, gc = (a & 1) ? g2[a / 2].y : g2[a / 2].x;
-        const V2<R> sa = v2_splat(ga), sb = v2_splat(gb), sc = v2_splat(gc);
-#pragma unroll
-        for (int k = 0; k <= a / 2; k++)
-          H[hp(2 * P0 + a, P0 + k)] = v2_fma(sa, tn[k], v2_fma(sb, t1[k], v2_fma(sc, t2[k], H[hp(2 * P0 + a, P0 + k)])));
-      }
-#else
       // three sweeps over the touched part of H, one frame axis each: a v_pk_fma_f32 feeding the next v_pk_fma_f32 costs a
       // wait state (s_nop) on gfx950; chained per entry the compiler left 166 of them in the loop, swept per axis the
       // dependent pair is a whole sweep apart
@@ -1255,13 +1261,48 @@ template <typename R, bool BLK> struct Sim {
         const V2<R>* tt = axis == 0 ? t2 : (axis == 1 ? t1 : tn);
 #pragma unroll
         for (int a = 0; a < 2 * NPA; a++) {
+          if (a / 2 == SKIP) continue;
           const V2<R> sg = v2_splat((a & 1) ? gg[a / 2].y : gg[a / 2].x);
 #pragma unroll
-          for (int k = 0; k <= a / 2; k++) H[hp(2 * P0 + a, P0 + k)] = v2_fma(sg, tt[k], H[hp(2 * P0 + a, P0 + k)]);
+          for (int k = 0; k <= a / 2; k++) {
+            if (k == SKIP) continue;
+            H[hp(2 * P0 + a, P0 + k)] = v2_fma(sg, tt[k], H[hp(2 * P0 + a, P0 + k)]);
+          }
         }
       }
-#endif
       return mk;
+    }
+
+    // one block<->robot contact into H / rhs.  A point of the torso patch does not see the wheel dofs: pair 3 of its G rows is
+    // zero and 14 of the 56 pair updates fall away; the wheel contact (its own slot, met once, outside the patch loop) takes
+    // the full form -- no per-iteration divergence between the two
+    template <bool WHEEL>
+    static BRS_HD void assemble_coupled(const Params<R>& P, Store<R>& st, const Frame& F, Masks& M, bool first, uint32_t srcC, int c,
+                                        Coupled& C, V2<R>* H, V2<R>* rhs2, const V2<R>* x2) {
+      coupled_load<WHEEL>(P, st, F, c, C);
+      V2<R> g[3][7];
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        R ct[3], cb[3];
+        cross_(C.rT, C.dT[k], ct);
+        cross_(C.rB, C.dB[k], cb);
+        g[k][0] = v2_make(-C.dT[k][0], -C.dT[k][1]); g[k][1] = v2_make(-C.dT[k][2], -ct[0]); g[k][2] = v2_make(-ct[1], -ct[2]);
+        if constexpr (WHEEL) {
+          const R wk = dot_(C.wc, C.dT[k]);
+          g[k][3] = v2_make(C.sel == 1 ? -wk : (R)0, C.sel == 2 ? -wk : (R)0);
+        } else
+          g[k][3] = v2_splat<R>((R)0);
+        g[k][4] = v2_make(C.dB[k][0], C.dB[k][1]); g[k][5] = v2_make(C.dB[k][2], cb[0]); g[k][6] = v2_make(cb[1], cb[2]);
+      }
+      int mk;
+      if constexpr (WHEEL) {
+        const bool ev = first && !(BRS_MASK_HINT && sel_wheel_contact(F.psels) == C.sel);
+        mk = contact_into<0, 7>(H, rhs2, g[0], g[1], g[2], C.mu, C.D, C.An, C.Bt1, C.Bt2, ev, get4(srcC, c), x2);
+      } else {
+        const bool ev = first && !(BRS_MASK_HINT && c < F.pnc);
+        mk = contact_into<0, 7, 3>(H, rhs2, g[0], g[1], g[2], C.mu, C.D, C.An, C.Bt1, C.Bt2, ev, get4(srcC, c), x2);
+      }
+      M.hC |= put4(mk, c);
     }
 
     // assemble H = M + sum_active D j j^T and rhs = M a0 + sum_active D aref j  (both on the packed-pair layout)
@@ -1322,24 +1363,8 @@ template <typename R, bool BLK> struct Sim {
           M.hB |= put4(mk, c);
         }
         Coupled C;
-        C.sel = -1;
-        for (int c = 0; c < F.nc; c++) {
-          coupled_load(P, st, F, c, C);
-          V2<R> g[3][7];
-#pragma unroll
-          for (int k = 0; k < 3; k++) {
-            R ct[3], cb[3];
-            cross_(C.rT, C.dT[k], ct);
-            cross_(C.rB, C.dB[k], cb);
-            R wk = dot_(C.wc, C.dT[k]);
-            g[k][0] = v2_make(-C.dT[k][0], -C.dT[k][1]); g[k][1] = v2_make(-C.dT[k][2], -ct[0]); g[k][2] = v2_make(-ct[1], -ct[2]);
-            g[k][3] = v2_make(C.sel == 1 ? -wk : (R)0, C.sel == 2 ? -wk : (R)0);
-            g[k][4] = v2_make(C.dB[k][0], C.dB[k][1]); g[k][5] = v2_make(C.dB[k][2], cb[0]); g[k][6] = v2_make(cb[1], cb[2]);
-          }
-          const bool ev = first && !(BRS_MASK_HINT && c < F.pnc && sel_coupled(F.psels, c) == C.sel);
-          int mk = contact_into<0, 7>(H, rhs2, g[0], g[1], g[2], C.mu, C.D, C.An, C.Bt1, C.Bt2, ev, get4(srcC, c), x2);
-          M.hC |= put4(mk, c);
-        }
+        for (int c = 0; c < F.nc; c++) assemble_coupled<false>(P, st, F, M, first, srcC, c, C, H, rhs2, x2);
+        if (sel_wheel_contact(F.sels)) assemble_coupled<true>(P, st, F, M, first, srcC, PATCH_MAX, C, H, rhs2, x2);
       }
     }
 
@@ -1486,7 +1511,7 @@ template <typename R, bool BLK> struct Sim {
     BRS_MARK("begin_tail");
     C.first = true; C.it = 0; C.cost = 0;
     C.M.hR = 0; C.M.hB = 0; C.M.hC = 0; C.M.nR = 0; C.M.nB = 0; C.M.nC = 0;
-    C.conv = F.nfr + F.nfb + F.nc == 0;
+    C.conv = F.nfr + F.nfb + F.nc == 0 && sel_wheel_contact(F.sels) == 0;
     if (C.conv) {  // no contacts: the unconstrained acceleration is the answer
 #pragma unroll
       for (int i = 0; i < NV; i++) { S.a[i] = F.a0[i]; C.fcon[i] = 0; }
