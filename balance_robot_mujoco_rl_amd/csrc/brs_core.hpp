@@ -861,10 +861,14 @@ template <typename R, bool BLK> struct Sim {
           }
           BRS_MARK("cc_reduce");
           // keep the PATCH_MAX = 6 deepest (ties: lower candidate index).  tau = 6th smallest valid g from a sorting network
-          // (sorted groups of 4, bitonic merges to two sorted octets, low half of their merge) -- branch-free: some lane of
-          // a wave needs it on most trips, and a per-lane selection loop would cost every lane its worst case
+          // (sorted groups of 4, bitonic merges to two sorted octets, low half of their merge) -- branch-free inside: a
+          // per-lane selection loop would cost every lane its worst case
           uint32_t keep = vmask;
+#if defined(BRS_ALWAYS_REDUCE)  // A/B only
           {
+#else
+          if (__builtin_popcount(vmask) > PATCH_MAX) {  // rare with 6 slots: a wave usually skips the network
+#endif
             R k_[16];
 #pragma unroll
             for (int q = 0; q < 16; q++) k_[q] = ((vmask >> q) & 1u) ? gq[q] : (R)1e30;
@@ -906,7 +910,7 @@ template <typename R, bool BLK> struct Sim {
               kp |= go ? lowbit : 0u;
               eq &= go ? ~lowbit : ~0u;
             }
-            keep = __builtin_popcount(vmask) > PATCH_MAX ? kp : vmask;
+            keep = __builtin_popcount(vmask) > PATCH_MAX ? kp : keep;
           }
           BRS_MARK("cc_scatter");
           const int nkeep = (int)__builtin_popcount(keep);
@@ -1349,6 +1353,7 @@ template <typename R, bool BLK> struct Sim {
         M.hR |= put4(mk, c);
       }
       if constexpr (BLK) {
+        BRS_MARK("asm_block_loop");
         for (int c = 0; c < F.nfb; c++) {
           int s = SLOT_BLOCK + c;
           R r[3] = {st.get(s, 0), st.get(s, 1), st.get(s, 2)};
@@ -1363,8 +1368,11 @@ template <typename R, bool BLK> struct Sim {
           M.hB |= put4(mk, c);
         }
         Coupled C;
+        BRS_MARK("asm_patch_loop");
         for (int c = 0; c < F.nc; c++) assemble_coupled<false>(P, st, F, M, first, srcC, c, C, H, rhs2, x2);
+        BRS_MARK("asm_wheel_contact");
         if (sel_wheel_contact(F.sels)) assemble_coupled<true>(P, st, F, M, first, srcC, PATCH_MAX, C, H, rhs2, x2);
+        BRS_MARK("asm_done");
       }
     }
 

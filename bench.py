@@ -101,6 +101,45 @@ def spawn_ranks(args):
     return proc.returncode if line is not None or proc.returncode else 1
 
 
+class SubBatches:
+    """--streams S: the envs of one GPU as S handles of n/S envs (contiguous global env indices, same Philox streams as
+    the single handle), each stepping on its own HIP stream.  step(k) enqueues one launch per handle and returns; there
+    is no barrier between the handles until the caller synchronises the device."""
+
+    def __init__(self, BatchedSim, args, n, S, dev, rank, actions):
+        m = n // S
+        self.m, self.S, self.dev = m, S, dev
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+        self.sims = [BatchedSim(args.env, m, device=dev.index, seed=0, env_index_base=rank * n + s * m, auto_reset=True,
+                                block_threads=args.block_threads, lane_grouping=not args.no_lane_grouping) for s in range(S)]
+        self.acts = [[a[s * m:(s + 1) * m].contiguous() for a in actions] for s in range(S)]
+        self.last_events = None
+
+    def reset(self):
+        for sim in self.sims:
+            sim.reset()
+        torch.cuda.synchronize(self.dev)
+
+    def step(self, k, timed=None):
+        for s, sim in enumerate(self.sims):
+            with torch.cuda.stream(self.streams[s]):
+                if timed is not None:
+                    timed[0][s].record()
+                sim.step(self.acts[s][k])
+                if timed is not None:
+                    timed[1][s].record()
+
+    @property
+    def terminated(self):
+        return torch.cat([sim.terminated for sim in self.sims])
+
+    def step_bytes_per_env(self):
+        return self.sims[0].step_bytes_per_env()
+
+    def step_kernel_name(self):
+        return self.sims[0].step_kernel_name()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,6 +153,10 @@ def main():
                          "drop, no contacts, first block in flight); the pre-roll runs until falls and auto-resets have "
                          "de-phased them and the per-step kernel time is stationary")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="split the envs of a GPU over this many handles, each stepping on its own HIP stream with no barrier "
+                         "between them until the end (asynchronous sub-batches: a finished sub-batch's SIMDs are back-filled "
+                         "by the next launch of another); 1 = one launch per step")
     ap.add_argument("--no-lane-grouping", action="store_true", help="A/B: keep env i on lane i (BRS_FLAG_NO_LANE_GROUPING)")
     args = ap.parse_args()
 
@@ -151,13 +194,21 @@ def main():
         dist.barrier()
     from balance_robot_mujoco_rl_amd import BatchedSim
     n = args.envs
-    sim = BatchedSim(args.env, n, device=dev.index, seed=0, env_index_base=rank * n, auto_reset=True,
-                     block_threads=args.block_threads, lane_grouping=not args.no_lane_grouping)
-    sim.reset()
+    S = args.streams
+    if S < 1 or n % S:
+        print(f"bench.py: --envs {n} is not divisible by --streams {S}", file=sys.stderr)
+        sys.exit(2)
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
     pool = 16
     actions = [(torch.rand((n, 2), generator=gen, device=dev) * 2 - 1).contiguous() for _ in range(pool)]
+    if S > 1:
+        sim = SubBatches(BatchedSim, args, n, S, dev, rank, actions)
+        actions = list(range(pool))  # SubBatches.step takes the index into its own per-handle action slices
+    else:
+        sim = BatchedSim(args.env, n, device=dev.index, seed=0, env_index_base=rank * n, auto_reset=True,
+                         block_threads=args.block_threads, lane_grouping=not args.no_lane_grouping)
+    sim.reset()
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -171,27 +222,42 @@ def main():
     win, cap = 50, max(args.preroll, 1500)
     win_ms = []
     while True:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(win):
-            sim.step(actions[kstep % pool]); kstep += 1
-        e1.record()
-        e1.synchronize()
-        win_ms.append(e0.elapsed_time(e1) / win)
+        if S > 1:  # no single stream sees all launches: wall clock around a synchronised window
+            torch.cuda.synchronize(dev)
+            tw = time.perf_counter()
+            for _ in range(win):
+                sim.step(actions[kstep % pool]); kstep += 1
+            torch.cuda.synchronize(dev)
+            win_ms.append((time.perf_counter() - tw) * 1e3 / win)
+        else:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(win):
+                sim.step(actions[kstep % pool]); kstep += 1
+            e1.record()
+            e1.synchronize()
+            win_ms.append(e0.elapsed_time(e1) / win)
         stationary = len(win_ms) >= 2 and abs(win_ms[-1] - win_ms[-2]) <= 0.02 * win_ms[-2]
         if (kstep >= args.preroll and stationary) or kstep >= cap:
             break
     preroll = kstep
     for _ in range(args.warmup):
         sim.step(actions[kstep % pool]); kstep += 1
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    if S > 1:
+        ev0 = [[torch.cuda.Event(enable_timing=True) for _ in range(S)] for _ in range(args.steps)]
+        ev1 = [[torch.cuda.Event(enable_timing=True) for _ in range(S)] for _ in range(args.steps)]
+    else:
+        ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+        ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        ev0[k].record()
-        sim.step(actions[kstep % pool]); kstep += 1
-        ev1[k].record()
+        if S > 1:
+            sim.step(actions[kstep % pool], timed=(ev0[k], ev1[k])); kstep += 1
+        else:
+            ev0[k].record()
+            sim.step(actions[kstep % pool]); kstep += 1
+            ev1[k].record()
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -199,14 +265,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     # HIP events on the stream the kernel is launched on (BatchedSim launches on torch's current stream)
-    kms = np.array([a.elapsed_time(b) for a, b in zip(ev0, ev1)])
+    if S > 1:  # per-launch durations of the sub-batch launches (they overlap: not additive)
+        kms = np.array([a.elapsed_time(b) for r0, r1 in zip(ev0, ev1) for a, b in zip(r0, r1)])
+    else:
+        kms = np.array([a.elapsed_time(b) for a, b in zip(ev0, ev1)])
     kern_ms = float(kms.mean())
     n_done = int(sim.terminated.sum().item())  # touches the outputs (also proves the last step ran)
 
     if rank == 0:
         total_envs = n * world
         value = total_envs * args.steps / elapsed
-        bytes_per_launch = sim.step_bytes_per_env() * n
+        bytes_per_launch = sim.step_bytes_per_env() * (n // S)
         achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
         out = {
             "metric": "env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
@@ -215,7 +284,7 @@ def main():
             "config": {"workload": f"{args.env}, {n} env instances per GPU ({total_envs} total), random policy "
                                    f"U(-1,1)^2, auto-reset on, 250 substeps of 2e-5 s per env step",
                        "envs_per_gpu": n, "substeps": 250, "parallelism": f"env-sharded x{world}, no collective",
-                       "lane_grouping": not args.no_lane_grouping, "preroll_steps": preroll, "preroll_window_ms_per_step": [round(x, 4) for x in win_ms]},
+                       "lane_grouping": not args.no_lane_grouping, "streams": S, "preroll_steps": preroll, "preroll_window_ms_per_step": [round(x, 4) for x in win_ms]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": sim.step_kernel_name(), "kernel_ms": kern_ms,
@@ -230,7 +299,7 @@ def main():
         # rocprofv3 summary of this exact workload exists, report its per-launch figure (separate --pmc passes,
         # FETCH_SIZE / WRITE_SIZE as MI355X_MICROARCH.md prescribes), else null
         try:
-            if args.env == "Env03-v2" and n == 65536:
+            if args.env == "Env03-v2" and n == 65536 and S == 1:
                 summ = json.load(open(os.path.join(ROOT, "profiles", "r02_env03_summary.json")))
                 out["roofline"]["traffic"] = summ["hbm_traffic"]["bytes_per_launch"]
                 out["roofline"]["valu"] = summ.get("valu")

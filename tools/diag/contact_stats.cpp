@@ -25,10 +25,13 @@ int main(int argc, char** argv) {
   std::vector<float> act(2 * N);
   std::mt19937 gen(1); std::uniform_real_distribution<float> U(-1, 1);
   Stats tot{};
+  long key_hist[8] = {0}, key_nc[8] = {0}, key_sat[8] = {0}, key_trips[8] = {0};
   long lane_steps = 0, lane_steps_reach = 0, lane_steps_nc = 0, wave_steps = 0, wave_steps_nc = 0, wave_steps_reach = 0, ndone = 0;
   for (int t = 0; t < STEPS; t++) {
     for (auto& a : act) a = U(gen);
     std::vector<Stats> per(N);
+    std::vector<int> key(N);
+    for (int i = 0; i < N; i++) { EnvState<R, true> S0; load_state<R, true>(S0, d.data(), f.data(), ii.data(), N, i); key[i] = cost_class<R, true>(P, S0); }
 #pragma omp parallel for schedule(dynamic, 4)
     for (int i = 0; i < N; i++) {
       R buf[LDS_WORDS_ENV03];
@@ -46,6 +49,7 @@ int main(int argc, char** argv) {
       const Stats& s = per[i];
       long* a = (long*)&tot; const long* b = (const long*)&s;
       for (size_t k = 0; k < sizeof(Stats) / sizeof(long); k++) a[k] += b[k];  // (last_iters ints are summed as garbage; unused)
+      key_hist[key[i]]++; key_nc[key[i]] += (s.nc_hist[1] + s.nc_hist[2] + s.nc_hist[3] + s.nc_hist[4] + s.nc_hist[5] + s.nc_hist[6] + s.nc_hist[7]) > 0; key_sat[key[i]] += s.cp_torso; key_trips[key[i]] += s.trips;
       lane_steps++; lane_steps_reach += s.cp_reach > 0; lane_steps_nc += s.cp_nc > 0 || (s.nc_hist[1] + s.nc_hist[2] + s.nc_hist[3] + s.nc_hist[4]) > 0;
     }
     for (int w = 0; w + 64 <= N; w += 64) {
@@ -63,6 +67,8 @@ int main(int argc, char** argv) {
   printf("\nnc :"); for (int k = 0; k < 5; k++) printf(" [%d]=%.4f", k, tot.nc_hist[k] / S);
   printf("\nlane-steps with any sphere-reach substep %.4f, with any coupled contact %.4f\n", (double)lane_steps_reach / lane_steps, (double)lane_steps_nc / lane_steps);
   printf("64-lane wave-steps with any reach %.4f, any coupled contact %.4f\n", (double)wave_steps_reach / wave_steps, (double)wave_steps_nc / wave_steps);
+  for (int k = 0; k < 8; k++) printf("key %d (floor %d wheel %d far %d): share %.4f  with coupled contact %.4f  torso-narrow substeps/step %.1f  trips/step %.1f\n", k, k & 1, (k >> 1) & 1, k >> 2,
+      (double)key_hist[k] / lane_steps, key_hist[k] ? (double)key_nc[k] / key_hist[k] : 0.0, key_hist[k] ? (double)key_sat[k] / key_hist[k] : 0.0, key_hist[k] ? (double)key_trips[k] / key_hist[k] : 0.0);
   printf("episodes finished %ld (mean length %.1f env steps)\n", ndone, (double)N * STEPS / std::max(1L, ndone));
   return 0;
 }

@@ -50,4 +50,12 @@ print(f"  last launch: cycles/trip mean {np.mean(cyc / trips):.0f} min {np.min(c
 for x in range(8):
     m = xcc == x
     if m.any(): print(f"    XCC {x}: waves {int(m.sum())} mean cycles {cyc[m].mean():.0f} max {cyc[m].max():.0f} cycles/trip {np.mean(cyc[m] / trips[m]):.0f}")
+# lanes are grouped by collision cost class in slot order (brs_group_kernel): wave index ~ bucket
+print("  by wave index (32 groups of 32 waves): mean cycles / max cycles / mean trips / cycles per trip")
+for gi in range(32):
+    sl = slice(32 * gi, 32 * gi + 32)
+    print(f"    waves {32 * gi:4d}-{32 * gi + 31:4d}: {cyc[sl].mean():10.0f} {cyc[sl].max():10.0f} {trips[sl].mean():7.1f} {np.mean(cyc[sl] / trips[sl]):7.0f}")
+order = np.argsort(-cyc)[:12]
+print("  slowest waves: " + ", ".join(f"#{int(i)}: {cyc[i]:.0f} cyc {trips[i]:.0f} trips" for i in order))
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 np.save(os.path.join(ROOT, "gpurun_out", "wave_records.npy"), w)
