@@ -401,3 +401,34 @@ def test_vec_env_on_the_gpu(devices):
         assert infos[int(np.flatnonzero(~dones)[0])] == {}
     assert ndone > 0
     env.close(); ref.close()
+
+
+def test_gymnasium_vector_adapter_on_the_gpu():
+    """BalanceVectorEnv (Gymnasium vector API) over a real handle: 5-tuple step, same-step auto-reset,
+    infos["final_observation"] / ["_final_observation"] for the finished envs -- against a plain BatchedSim"""
+    import torch
+    from balance_robot_mujoco_rl_amd import BatchedSim
+    from balance_robot_mujoco_rl_amd.vec_env import BalanceVectorEnv
+    n = 192
+    env = BalanceVectorEnv("Env03-v2", n, devices=[0], seed=5)
+    ref = BatchedSim("Env03-v2", n, device=0, seed=5, auto_reset=True)
+    obs, infos = env.reset(seed=5)
+    assert infos == {}
+    np.testing.assert_array_equal(obs, ref.reset().cpu().numpy())
+    rng = np.random.default_rng(1)
+    nfinal = 0
+    for _ in range(40):
+        a = rng.uniform(-1, 1, size=(n, 2)).astype(np.float32)
+        obs, rew, term, trunc, infos = env.step(a)
+        ro, rr, rte, rtr, rto = [x.cpu().numpy() for x in ref.step(torch.from_numpy(a).cuda())]
+        np.testing.assert_array_equal(obs, ro); np.testing.assert_array_equal(rew, rr)
+        np.testing.assert_array_equal(term, rte.astype(bool)); np.testing.assert_array_equal(trunc, rtr.astype(bool))
+        done = term | trunc
+        if done.any():
+            np.testing.assert_array_equal(infos["_final_observation"], done)
+            for i in np.flatnonzero(done):
+                np.testing.assert_array_equal(infos["final_observation"][i], rto[i]); nfinal += 1
+        else:
+            assert "final_observation" not in infos
+    assert nfinal > 0
+    env.close(); ref.close()
