@@ -64,8 +64,9 @@ def _mk(env_id, n, **kw):
                env_index_base=kw.get("env_index_base", 0))
     if "obs_noise" in kw:
         okw["noise"] = kw["obs_noise"]
-    if "max_episode_steps" in kw:
-        okw["max_episode_steps"] = kw["max_episode_steps"]
+    for k in ("max_episode_steps", "substeps", "timestep"):
+        if k in kw:
+            okw[k] = kw[k]
     orc = O.Oracle(env_id, n, **okw)
     return torch, sim, orc
 
@@ -432,3 +433,55 @@ def test_gymnasium_vector_adapter_on_the_gpu():
             assert "final_observation" not in infos
     assert nfinal > 0
     env.close(); ref.close()
+
+
+@pytest.mark.parametrize("env_id", ["Env03-v2", "Env01-v2"])
+def test_runtime_parameter_kernel_with_non_default_timestep(env_id):
+    """brs_config.timestep / .substeps other than the reference's 2e-5 s x 250: the handle runs the kernel whose model
+    constants are kernel ARGUMENTS (the per-id kernels fold the default ones at compile time).  Same gates vs the oracle
+    created with the same settings (100 substeps of 5e-5 s = the same 5 ms env step)"""
+    n, steps = 256, 60
+    torch, sim, orc = _mk(env_id, n, seed=2, auto_reset=True, obs_noise=False, substeps=100, timestep=5e-5)
+    assert "-1>" in sim.step_kernel_name(), sim.step_kernel_name()
+    sim.reset(); orc.reset()
+    rng = np.random.default_rng(7)
+    g = Gates()
+    for t in range(steps):
+        qpos, qvel, warm, tm = orc.get_state()
+        sim.set_state(qpos, qvel, warm, tm); sim.set_aux(orc.get_aux()); sim.set_xpose(*orc.get_xpose())
+        act = rng.uniform(-1, 1, size=(n, 2)).astype(np.float32)
+        og = [x.cpu().numpy().copy() for x in sim.step(torch.from_numpy(act).cuda())]
+        oo = orc.step(act)
+        skip = og[2].astype(bool) | og[3].astype(bool) | oo[2] | oo[3]
+        skip |= np.isnan(sim.get_aux()[:, 1]) != np.isnan(orc.get_aux()[:, 1])
+        g.add(qpos, sim.get_state()[0], orc.get_state()[0], skip)
+        assert np.array_equal(sim.get_state()[3][~skip], orc.get_state()[3][~skip]), "time = 100 fp64 additions of 5e-5"
+    g.check(env_id + " (5e-5 s x 100)")
+    sim.close(); orc.close()
+
+
+def test_folded_and_runtime_constant_kernels_agree(monkeypatch):
+    """the same default model through both kernel families: constants folded at compile time (default) and passed as kernel
+    arguments (BRS_NO_FOLD=1).  Same arithmetic on the same constants up to how the compiler contracts literal operands:
+    trajectories agree to rounding"""
+    import torch
+    from balance_robot_mujoco_rl_amd import BatchedSim
+    n = 512
+    a = BatchedSim("Env03-v2", n, seed=9, auto_reset=True)
+    monkeypatch.setenv("BRS_NO_FOLD", "1")
+    b = BatchedSim("Env03-v2", n, seed=9, auto_reset=True)
+    monkeypatch.delenv("BRS_NO_FOLD")
+    assert a.step_kernel_name() != b.step_kernel_name()
+    np.testing.assert_array_equal(a.reset().cpu().numpy(), b.reset().cpu().numpy())
+    gen = torch.Generator(device="cuda"); gen.manual_seed(3)
+    worst = 0.0
+    for _ in range(20):
+        act = torch.rand((n, 2), generator=gen, device="cuda") * 2 - 1
+        qa = a.get_state(); b.set_state(*qa); b.set_aux(a.get_aux()); b.set_xpose(*a.get_xpose())
+        oa = [x.cpu().numpy().copy() for x in a.step(act)]
+        ob = [x.cpu().numpy().copy() for x in b.step(act)]
+        keep = ~(oa[2].astype(bool) | oa[3].astype(bool) | ob[2].astype(bool) | ob[3].astype(bool))
+        assert int((oa[2] != ob[2]).sum()) <= 1
+        worst = max(worst, float(np.abs(a.get_state()[0][keep, :9] - b.get_state()[0][keep, :9]).max()))
+    assert worst < 1e-5, worst
+    a.close(); b.close()
