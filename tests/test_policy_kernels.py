@@ -163,3 +163,36 @@ def test_device_rollout_runs_without_leaving_the_gpu_and_matches_a_stepwise_repl
     for x, y, name in zip(a, b, ("obs", "action", "logp", "value", "reward", "episode_start", "adv", "ret")):
         np.testing.assert_allclose(x.cpu().numpy().astype(np.float64), y.cpu().numpy().astype(np.float64), rtol=1e-5, atol=1e-5, err_msg=name)
     assert int(a[5][1:].sum()) > 0, "episodes must end inside the rollout (time limit 15)"
+
+
+@pytest.mark.gpu
+def test_device_resident_weights_are_read_in_place():
+    """brs_policy_use_device_weights: the kernel reads the learner's flat parameter tensor where it lives -- an in-place
+    update (an optimiser step) is seen by the next call without any copy; set_weights switches back to the handle's own copy"""
+    import torch
+    from balance_robot_mujoco_rl_amd.policy import DevicePolicy, NPARAM
+    g = torch.Generator().manual_seed(1)
+    flat = (torch.randn(NPARAM, generator=g) * 0.2).float()
+    obs = torch.randn(1000, 6, generator=g).float().cuda()
+    host = DevicePolicy(device=0, seed=2)
+    host.set_weights(flat.numpy())
+    ref = [t.clone() for t in host.act(obs, step=7)]
+    dev_params = flat.cuda().contiguous()
+    pol = DevicePolicy(device=0, seed=2)
+    pol.use_device_weights(dev_params)
+    out = pol.act(obs, step=7)
+    for a, b in zip(out, ref):
+        assert torch.equal(a, b)
+    dev_params.mul_(0.5)                       # "optimiser step" in place
+    host.set_weights((flat * 0.5).numpy())
+    ref2 = [t.clone() for t in host.act(obs, step=7)]
+    out2 = [t.clone() for t in pol.act(obs, step=7)]
+    for a, b in zip(out2, ref2):
+        assert torch.equal(a, b)
+    assert not torch.equal(out2[0], ref[0])
+    with pytest.raises(ValueError):
+        pol.use_device_weights(dev_params[:-1])
+    pol.set_weights(flat.numpy())              # back to the handle's own copy
+    for a, b in zip(pol.act(obs, step=7), ref):
+        assert torch.equal(a, b)
+    host.close(); pol.close()
