@@ -55,6 +55,29 @@ template <int VARIANT> __device__ __forceinline__ Params<float> fold_params(cons
   }
 }
 
+// Lane grouping (Env03): after every step the envs are regrouped along the lanes by the cost class of their NEXT step
+// (brs_state.hpp: cost_class).  Bucket order along the lanes:
+//     floor | far A | near (plain) | far B | wheel | floor + wheel
+// "far" lanes (no block<->robot work at all; split by env parity into A and B) are put between the classes: a boundary wave
+// then pays one expensive path, not two.  The step kernel counts its lanes per bucket as it retires (wave-aggregated atomics
+// into 6 counters behind the lane map), brs_group_kernel turns the counts into bucket bases and hands out the slots with
+// wave-aggregated cursors: a few microseconds over 256 workgroups.  (Round 2a: a stable counting sort in ONE workgroup,
+// 95 us = 2 % of the step.)  The order inside a bucket depends on the order the atomics arrive in -- an env's arithmetic does
+// not depend on its lane, so results stay bit-identical (test_determinism_and_shard_invariance).
+constexpr int NBUCKET = 6;
+__device__ __forceinline__ int bucket_of(int key, int e) {
+  const int k = key & 3;
+  if (k == 1) return 0;
+  if (k == 2) return 4;
+  if (k == 3) return 5;
+  return (key & 4) ? ((e & 1) ? 3 : 1) : 2;
+}
+// counters behind the lane map and the keys: cnt[NBUCKET] (lanes per bucket, filled by the step kernel), cursor[NBUCKET], ticket
+constexpr int GROUP_WORDS = 16;
+template <bool BLK> __device__ __forceinline__ unsigned* group_counters(int* ii, int N) {
+  return (unsigned*)(ii + ((size_t)Layout<BLK>::NI + 2) * N);
+}
+
 template <bool BLK, int VARIANT>
 __device__ __forceinline__ void step_body(const Params<float>& Prt, const int N, double* __restrict__ d, float* __restrict__ f,
                                           int* __restrict__ ii, const float* __restrict__ actions, float* __restrict__ obs,
@@ -91,7 +114,16 @@ __device__ __forceinline__ void step_body(const Params<float>& Prt, const int N,
   int te, tr, cls = 0;
   env_step_idx<float, BLK, float, LaneIndex>(P, st, rng, d, f, ii, (size_t)N, idx, a0, a1, o, to, rew, te, tr, BLK ? &cls : nullptr);
   const size_t i = idx.get();
-  if constexpr (BLK) ((uint8_t*)(ii + ((size_t)Layout<BLK>::NI + 1) * N))[i] = (uint8_t)cls;
+  if constexpr (BLK) {
+    ((uint8_t*)(ii + ((size_t)Layout<BLK>::NI + 1) * N))[i] = (uint8_t)cls;
+    const int b = bucket_of(cls, (int)i);
+    unsigned* cnt = group_counters<BLK>(ii, N);
+#pragma unroll
+    for (int k = 0; k < NBUCKET; k++) {
+      const unsigned long long m = __ballot(b == k);
+      if (m != 0ull && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)m) - 1)) atomicAdd(&cnt[k], (unsigned)__popcll(m));
+    }
+  }
 #if defined(BRS_TIMING) && defined(__HIP_DEVICE_COMPILE__)
   if ((threadIdx.x & 63) == 0) {
     for (int k = 0; k < 12; k++) atomicAdd(&brs_dbg[k], brs_tim_slots()[k]);
@@ -166,69 +198,51 @@ __global__ void __launch_bounds__(256) brs_physics_kernel(const Params<float> P,
   physics_mem<float, BLK, float>(P, st, d, f, ii, (size_t)N, (size_t)i, ctrl[2 * (size_t)i], ctrl[2 * (size_t)i + 1], nsub);
 }
 
-// stable counting sort of the envs by cost class -> perm[lane slot] = env.  ONE workgroup of 1024 threads: thread t owns the
-// contiguous chunk [t * per, (t + 1) * per) of envs; LDS holds the per-(bucket, thread) counts, scanned bucket-major.
-// 65,536 keys = 64 per thread: a few microseconds, once per env step.
-// Bucket order along the lanes (keys: brs_state.hpp cost_class):
-//     floor | far A | near (plain) | far B | wheel | floor + wheel
-// A wave pays for every path one of its lanes walks, and the slowest wave ends the launch.  Measured with four buckets:
-// the pure rare-class waves were fine (floor 0.70x, wheel 0.9x, both 1.09x the plain wave) -- the two slowest waves of the
-// launch (1.19x) were the BOUNDARY waves where plain lanes with a full block<->robot patch sat next to rare-class lanes.
-// "far" lanes (no block<->robot work at all; split by env parity into A and B) are put between the classes: a boundary wave
-// then pays one expensive path, not two.
-constexpr int NBUCKET = 6;
-__device__ __forceinline__ int bucket_of(int key, int e) {
-#if defined(BRS_CLASS_V2)
-  const int k = key & 3;
-  return k == 0 ? 2 : (k == 1 ? 0 : (k == 2 ? 4 : 5));
-#else
-  const int k = key & 3;
-  if (k == 1) return 0;
-  if (k == 2) return 4;
-  if (k == 3) return 5;
-  return (key & 4) ? ((e & 1) ? 3 : 1) : 2;
-#endif
-}
-__global__ void __launch_bounds__(1024) brs_group_kernel(const int N, const uint8_t* __restrict__ keys, int* __restrict__ perm) {
-  __shared__ int cnt[NBUCKET * 1024];
-  __shared__ int part[1024];
-  const int t = threadIdx.x, per = (N + 1023) / 1024, lo = t * per, hi = min(N, lo + per);
-  int c[NBUCKET];
+constexpr int GROUP_THREADS = 256, GROUP_ENVS = 1024;  // small workgroups (they have to find room between step-kernel waves
+                                                       // when several handles share a GPU), 4 envs per thread
+__global__ void __launch_bounds__(GROUP_THREADS) brs_group_kernel(const int N, const uint8_t* __restrict__ keys, int* __restrict__ perm,
+                                                                  unsigned* __restrict__ ctr) {
+  // ONE slot request per workgroup and bucket: same-address device atomics are the cost of this kernel (one request per
+  // wave: 61 us for 65,536 envs; per 1,024 envs: 7 us).  Wave counts -> LDS -> exclusive offsets inside the workgroup
+  constexpr int NV = GROUP_ENVS / 64;  // 64-env groups of the workgroup ("virtual waves": 4 passes x 4 waves)
+  __shared__ unsigned wcnt[NV][NBUCKET], woff[NBUCKET];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int b[GROUP_ENVS / GROUP_THREADS];
+  unsigned long long mine[GROUP_ENVS / GROUP_THREADS];
 #pragma unroll
-  for (int k = 0; k < NBUCKET; k++) c[k] = 0;
-  for (int e = lo; e < hi; e++) {
-    const int b = bucket_of(keys[e], e);
+  for (int j = 0; j < GROUP_ENVS / GROUP_THREADS; j++) {
+    const int e = blockIdx.x * GROUP_ENVS + j * GROUP_THREADS + threadIdx.x;
+    b[j] = e < N ? bucket_of(keys[e], e) : -1;
+    mine[j] = 0ull;
 #pragma unroll
-    for (int k = 0; k < NBUCKET; k++) c[k] += b == k;
+    for (int k = 0; k < NBUCKET; k++) {
+      const unsigned long long m = __ballot(b[j] == k);
+      if (lane == 0) wcnt[j * (GROUP_THREADS / 64) + w][k] = (unsigned)__popcll(m);
+      mine[j] = b[j] == k ? m : mine[j];
+    }
   }
-#pragma unroll
-  for (int k = 0; k < NBUCKET; k++) cnt[k * 1024 + t] = c[k];
   __syncthreads();
-  // exclusive scan of the NBUCKET * 1024 counts (bucket-major): NBUCKET values per thread + Hillis-Steele over the threads
-  int v[NBUCKET], sum = 0;
-#pragma unroll
-  for (int k = 0; k < NBUCKET; k++) { v[k] = cnt[NBUCKET * t + k]; sum += v[k]; }
-  part[t] = sum;
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {
-    const int add = t >= off ? part[t - off] : 0;
-    __syncthreads();
-    part[t] += add;
-    __syncthreads();
+  if (threadIdx.x < NBUCKET) {  // thread k: bucket base from the step kernel's counts, this workgroup's share of the cursor
+    const int k = threadIdx.x;
+    unsigned base = 0, tot = 0;
+    for (int j = 0; j < k; j++) base += ctr[j];
+    for (int v = 0; v < NV; v++) { const unsigned c = wcnt[v][k]; wcnt[v][k] = tot; tot += c; }  // exclusive over the 64-env groups
+    woff[k] = base + (tot ? atomicAdd(&ctr[NBUCKET + k], tot) : 0u);
   }
-  int run = part[t] - sum;
-#pragma unroll
-  for (int k = 0; k < NBUCKET; k++) { const int x = v[k]; cnt[NBUCKET * t + k] = run; run += x; }
   __syncthreads();
-  int pos[NBUCKET];
 #pragma unroll
-  for (int k = 0; k < NBUCKET; k++) pos[k] = cnt[k * 1024 + t];
-  for (int e = lo; e < hi; e++) {
-    const int b = bucket_of(keys[e], e);
-    int p = 0;
+  for (int j = 0; j < GROUP_ENVS / GROUP_THREADS; j++) {
+    const int e = blockIdx.x * GROUP_ENVS + j * GROUP_THREADS + threadIdx.x;
+    if (b[j] >= 0) perm[woff[b[j]] + wcnt[j * (GROUP_THREADS / 64) + w][b[j]] + (unsigned)__popcll(mine[j] & ((1ull << lane) - 1ull))] = e;
+  }
+  // the last workgroup to finish clears the counters for the next step (every other one has read them by then)
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(&ctr[2 * NBUCKET], 1u) == gridDim.x - 1) {
 #pragma unroll
-    for (int k = 0; k < NBUCKET; k++) { p = b == k ? pos[k] : p; pos[k] += b == k; }
-    perm[p] = e;
+      for (int k = 0; k <= 2 * NBUCKET; k++) ctr[k] = 0u;
+    }
   }
 }
 
@@ -249,6 +263,7 @@ struct brs_handle {
   bool grouping = false;     // Env03: regroup lanes by cost class after every step (perm / keys live behind the int state)
   int* perm() const { return ii + ni; }                            // [N] lane slot -> env
   uint8_t* keys() const { return (uint8_t*)(ii + ni + (size_t)N); }  // [N] cost class of every env for its next step
+  unsigned* counters() const { return (unsigned*)(ii + ni + 2 * (size_t)N); }  // [GROUP_WORDS] bucket counts, cursors, ticket
   std::string err;
 };
 
@@ -340,7 +355,7 @@ int brs_create(const brs_config* cfg, brs_handle** out) {
   // + 7 fp64 scratch columns addressed by lane slot (accessor pose parked during the last substep, brs_state.hpp: LaneIndex)
   if (hipMalloc(&h->d, (h->nd + 7 * N) * sizeof(double)) != hipSuccess) return bail("brs_create: hipMalloc(fp64 state) failed");
   if (hipMalloc(&h->f, h->nf * sizeof(float)) != hipSuccess) return bail("brs_create: hipMalloc(fp32 state) failed");
-  if (hipMalloc(&h->ii, (h->ni + 2 * N) * sizeof(int)) != hipSuccess) return bail("brs_create: hipMalloc(int state) failed");
+  if (hipMalloc(&h->ii, (h->ni + 2 * N + GROUP_WORDS) * sizeof(int)) != hipSuccess) return bail("brs_create: hipMalloc(int state) failed");
   std::vector<double> d(h->nd);
   std::vector<float> f(h->nf);
   std::vector<int> ii(h->ni);
@@ -352,6 +367,7 @@ int brs_create(const brs_config* cfg, brs_handle** out) {
     std::vector<int> id(2 * N, 0);
     for (size_t k = 0; k < N; k++) id[k] = (int)k;
     if (hipMemcpy(h->perm(), id.data(), 2 * N * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return bail("brs_create: lane map init failed");
+    if (hipMemset(h->counters(), 0, GROUP_WORDS * sizeof(int)) != hipSuccess) return bail("brs_create: counter init failed");
     h->grouping = h->blk && !(cfg->flags & BRS_FLAG_NO_LANE_GROUPING);
     h->folded = !(cfg->timestep > 0 && cfg->timestep != 2e-5) && !std::getenv("BRS_NO_FOLD");
     h->occ2 = !h->blk && std::getenv("BRS_ENV01_OCC1") == nullptr;
@@ -437,7 +453,10 @@ int brs_step(brs_handle* h, const float* actions_dev, float* obs_dev, float* rew
   }
 #undef BRS_LAUNCH_STEP
 #undef BRS_LAUNCH_OCC2
-  if (h->grouping) hipLaunchKernelGGL(brs_group_kernel, dim3(1), dim3(1024), 0, s, h->N, h->keys(), h->perm());  // lanes of the NEXT step
+  if (h->blk) {  // lanes of the NEXT step; without grouping the counts the step kernel left are just cleared
+    if (h->grouping) hipLaunchKernelGGL(brs_group_kernel, dim3((h->N + GROUP_ENVS - 1) / GROUP_ENVS), dim3(GROUP_THREADS), 0, s, h->N, h->keys(), h->perm(), h->counters());
+    else (void)hipMemsetAsync(h->counters(), 0, GROUP_WORDS * sizeof(int), s);
+  }
   BRS_HIP_TRY(h, hipGetLastError());
   return BRS_OK;
 }
