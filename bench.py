@@ -303,6 +303,16 @@ def main():
                 summ = json.load(open(os.path.join(ROOT, "profiles", "r02_env03_summary.json")))
                 out["roofline"]["traffic"] = summ["hbm_traffic"]["bytes_per_launch"]
                 out["roofline"]["valu"] = summ.get("valu")
+                if out["roofline"]["valu"]:
+                    # the resource that does bind: VALU issue.  Instructions per wave-step from the committed PMC run, time from
+                    # THIS run; peak = one VALU instruction per 4 clocks per SIMD at the 2.4 GHz boost clock, 1,024 SIMDs
+                    v = dict(out["roofline"]["valu"])
+                    waves = (n + 63) // 64
+                    rate = v["valu_insts_per_wave_per_step"] * waves / (kern_ms * 1e-3)
+                    v["valu_wave_insts_per_s"] = rate
+                    v["peak_valu_wave_insts_per_s"] = 1024 * 2.4e9 / 4
+                    v["issue_frac_of_peak_at_2.4GHz"] = rate / v["peak_valu_wave_insts_per_s"]
+                    out["roofline"]["valu"] = v
                 out["roofline"]["traffic_source"] = "profiles/r02_env03_summary.json (rocprofv3 --pmc, same command line)"
         except Exception:
             pass
