@@ -102,6 +102,18 @@ BRS_HD float rcp_(float x) {
 #endif
 }
 BRS_HD double rcp_(double x) { return 1.0 / x; }
+// sqrt of a double in [0, ~1] without the (slow) fp64 sqrt on the device: v_rsq_f32 seed + two Newton steps in fp64
+BRS_HD double sqrt64_(double s) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (!(s > 1e-30)) return 0.0;
+  double y = (double)__builtin_amdgcn_rsqf((float)s);
+  y = y * (1.5 - 0.5 * s * y * y);
+  y = y * (1.5 - 0.5 * s * y * y);
+  return s * y;
+#else
+  return sqrt(s);
+#endif
+}
 BRS_HD float abs_(float x) { return fabsf(x); }
 BRS_HD double abs_(double x) { return fabs(x); }
 BRS_HD float atan2_(float y, float x) { return atan2f(y, x); }
@@ -481,8 +493,22 @@ template <typename R, bool BLK> struct Sim {
   }
 
   // plane <-> cylinder (the two wheels), restating MuJoCo's primitive in the torso frame
+  // The DISTANCES of the rim points -- the numbers that decide whether a contact point exists in this substep -- come from
+  // the fp64 pose (Floor64, built once per substep): a wheel resting on the floor has dist ~ -1e-4 m as the difference of two
+  // numbers of 3e-2 m, and in fp32 its rounding (~1e-8 m) decides on which 20-us substep a rim point switches on or off when
+  // the robot rocks; that one-substep disagreement with the fp64 oracle was the source of most robot-coordinate outliers
+  // above 1e-4.  ~40 fp64 operations per substep, no fp64 sqrt or division.
+  struct Floor64 { double nx, ny, nz, len, zT; };
+  static BRS_HD Floor64 floor64(const Params<R>& P, const ES& S) {
+    const double w = S.q[0], x = S.q[1], y = S.q[2], z = S.q[3];
+    Floor64 G;
+    G.nx = 2 * (x * z - w * y); G.ny = 2 * (y * z + w * x); G.nz = 1 - 2 * (x * x + y * y);
+    G.len = sqrt64_(G.ny * G.ny + G.nz * G.nz);
+    G.zT = S.p[2] - P.floor_z_d;
+    return G;
+  }
   static BRS_HD void collide_wheel(const Params<R>& P, Store<R>& st, Frame& F, const R* u, const R* w, const R* ww,
-                                   R zT, int sel, bool triangles) {
+                                   R zT, int sel, bool triangles, const Floor64& G) {
     const ContactClass<R>& c = P.cc[CC_WHEEL_FLOOR];
     R px = sel == 1 ? -P.wheel_px : P.wheel_px, pz = P.wheel_pz;
     R nx = F.nT()[0], ny = F.nT()[1], nz = F.nT()[2];
@@ -491,21 +517,29 @@ template <typename R, bool BLK> struct Sim {
     if (len >= (R)1e-15) { R k = P.wheel_r * rcp_(len); vy = -ny * k; vz = -nz * k; }
     else { vy = 0; vz = -P.wheel_r; }
     R sg = nx > 0 ? (R)-1 : (R)1;  // cylinder axis (body x) flipped to point towards the plane
-    R axh = sg * P.wheel_hl, prjaxis = -abs_(nx) * P.wheel_hl, prjvec = vy * ny + vz * nz;
+    R axh = sg * P.wheel_hl;
+#if defined(BRS_FLOOR_DIST32)  // A/B: round-2a behaviour
+    R prjaxis = -abs_(nx) * P.wheel_hl, prjvec = vy * ny + vz * nz;
     R dist0 = zT + nx * px + nz * pz;
-    R d1 = dist0 + prjaxis + prjvec;
-    if (!(d1 < c.margin)) return;
+    const R d1 = dist0 + prjaxis + prjvec, d2 = dist0 - prjaxis + prjvec, dT = dist0 + prjaxis - (R)0.5 * prjvec;
+    const bool in1 = d1 < c.margin, in2 = d2 < c.margin, inT = dT < c.margin;
+#else
+    const double prjaxis = -abs_(G.nx) * (double)P.wheel_hl, prjvec = -(double)P.wheel_r * G.len;  // vy ny + vz nz = -r len
+    const double dist0 = G.zT + G.nx * (double)px + G.nz * (double)pz;
+    const double d1d = dist0 + prjaxis + prjvec, d2d = dist0 - prjaxis + prjvec, dTd = dist0 + prjaxis - 0.5 * prjvec;
+    const bool in1 = d1d < (double)c.margin, in2 = d2d < (double)c.margin, inT = dTd < (double)c.margin;
+    const R d1 = (R)d1d, d2 = (R)d2d, dT = (R)dTd;
+#endif
+    if (!in1) return;
     if (!triangles) {
       R p1[3] = {px + axh, vy, pz + vz};
       add_robot_floor(P, st, F, u, w, ww, sel, CC_WHEEL_FLOOR, p1, d1);
-      R d2 = dist0 - prjaxis + prjvec;
-      if (d2 < c.margin) {
+      if (in2) {
         R p2[3] = {px - axh, vy, pz + vz};
         add_robot_floor(P, st, F, u, w, ww, sel, CC_WHEEL_FLOOR, p2, d2);
       }
     } else {
-      R dT = dist0 + prjaxis - (R)0.5 * prjvec;
-      if (dT < c.margin) {
+      if (inT) {
         const R k = (R)0.86602540378443864676;  // sqrt(3)/2 ; vec1 = sg*k*(0, vz, -vy)
         R pa[3] = {px + axh, sg * k * vz - (R)0.5 * vy, pz - sg * k * vy - (R)0.5 * vz};
         add_robot_floor(P, st, F, u, w, ww, sel, CC_WHEEL_FLOOR, pa, dT);
@@ -520,12 +554,12 @@ template <typename R, bool BLK> struct Sim {
   // first 4 in index order (MuJoCo's plane-box primitive).  Returns the count and the indices packed 3 bits each, so that
   // the (expensive) contact records are built by a loop over the PRESENT corners only: lanes of a wave hold boxes in
   // different orientations, an unrolled 8-corner loop would run the record code for every corner some lane uses.
-  static BRS_HD int box_corners(R nx, R ny, R nz, R sx, R sy, R sz, R dc, R margin, int& list) {
+  template <typename T> static BRS_HD int box_corners(T nx, T ny, T nz, T sx, T sy, T sz, T dc, T margin, int& list) {
     int cnt = 0;
     list = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-      R ld = ((i & 1) ? nx : -nx) * sx + ((i & 2) ? ny : -ny) * sy + ((i & 4) ? nz : -nz) * sz;
+      T ld = ((i & 1) ? nx : -nx) * sx + ((i & 2) ? ny : -ny) * sy + ((i & 4) ? nz : -nz) * sz;
       bool hit = dc + ld < margin && ld <= 0 && cnt < 4;
       list |= hit ? (i << (3 * cnt)) : 0;
       cnt += hit ? 1 : 0;
@@ -533,32 +567,36 @@ template <typename R, bool BLK> struct Sim {
     return cnt;
   }
   // plane <-> torso box
-  static BRS_HD void collide_torso(const Params<R>& P, Store<R>& st, Frame& F, const R* u, const R* w, const R* ww, R zT) {
+  static BRS_HD void collide_torso(const Params<R>& P, Store<R>& st, Frame& F, const R* u, const R* w, const R* ww, R zT, const Floor64& G) {
     const ContactClass<R>& c = P.cc[CC_TORSO_FLOOR];
     R nx = F.nT()[0], ny = F.nT()[1], nz = F.nT()[2];
     R dc = zT + nz * P.torso_cz;
     // cheap reject: lowest corner
     R low = dc - (abs_(nx) * P.torso_sx + abs_(ny) * P.torso_sy + abs_(nz) * P.torso_sz);
-    if (!(low < c.margin)) return;
-    int list, cnt = box_corners(nx, ny, nz, P.torso_sx, P.torso_sy, P.torso_sz, dc, c.margin, list);
+    if (!(low < c.margin + (R)1e-6)) return;  // (fp32 reject with slack; the decisions below are made in fp64)
+    const double dcd = G.zT + G.nz * (double)P.torso_cz;
+    int list, cnt = box_corners<double>(G.nx, G.ny, G.nz, (double)P.torso_sx, (double)P.torso_sy, (double)P.torso_sz, dcd, (double)c.margin, list);
     for (int k = 0; k < cnt; k++) {
       int i = (list >> (3 * k)) & 7;
       R lx = (i & 1) ? P.torso_sx : -P.torso_sx, ly = (i & 2) ? P.torso_sy : -P.torso_sy, lz = (i & 4) ? P.torso_sz : -P.torso_sz;
-      R d = dc + nx * lx + ny * ly + nz * lz;
+      R d = (R)(dcd + G.nx * (double)lx + G.ny * (double)ly + G.nz * (double)lz);
       R pt[3] = {lx, ly, P.torso_cz + lz};
       add_robot_floor(P, st, F, u, w, ww, 0, CC_TORSO_FLOOR, pt, d);
     }
   }
-  static BRS_HD void collide_block_floor(const Params<R>& P, Store<R>& st, Frame& F, const R* uB, const R* wB, R zB) {
+  static BRS_HD void collide_block_floor(const Params<R>& P, Store<R>& st, Frame& F, const ES& S, const R* uB, const R* wB, R zB) {
     const ContactClass<R>& c = P.cc[CC_BLOCK_FLOOR];
     R nx = F.nB()[0], ny = F.nB()[1], nz = F.nB()[2], s = P.block_s;
     R low = zB - (abs_(nx) + abs_(ny) + abs_(nz)) * s;
-    if (!(low < c.margin)) return;
-    int list, cnt = box_corners(nx, ny, nz, s, s, s, zB, c.margin, list);
+    if (!(low < c.margin + (R)1e-6)) return;  // (fp32 reject with slack; the decisions below are made in fp64, see Floor64)
+    const double qw = S.bq[0], qx = S.bq[1], qy = S.bq[2], qz = S.bq[3];
+    const double nxd = 2 * (qx * qz - qw * qy), nyd = 2 * (qy * qz + qw * qx), nzd = 1 - 2 * (qx * qx + qy * qy);
+    const double zBd = S.bp[2] - P.floor_z_d, sd = (double)s;
+    int list, cnt = box_corners<double>(nxd, nyd, nzd, sd, sd, sd, zBd, (double)c.margin, list);
     for (int k = 0; k < cnt; k++) {
       int i = (list >> (3 * k)) & 7;
       R lx = (i & 1) ? s : -s, ly = (i & 2) ? s : -s, lz = (i & 4) ? s : -s;
-      R d = zB + nx * lx + ny * ly + nz * lz;
+      R d = (R)(zBd + nxd * (double)lx + nyd * (double)ly + nzd * (double)lz);
       R r[3] = {lx - nx * d * (R)0.5, ly - ny * d * (R)0.5, lz - nz * d * (R)0.5};
       R wr[3];
       cross_(wB, r, wr);
@@ -1502,17 +1540,18 @@ template <typename R, bool BLK> struct Sim {
     BRS_TIC(1);
     BRS_MARK("begin_collide_robot");
     // collision: robot <-> floor.  Slot priority: wheel main points, torso corners, wheel triangle points
-    collide_wheel(P, st, F, u, S.w, S.ww, zT, 1, false);
-    collide_wheel(P, st, F, u, S.w, S.ww, zT, 2, false);
-    collide_torso(P, st, F, u, S.w, S.ww, zT);
-    collide_wheel(P, st, F, u, S.w, S.ww, zT, 1, true);
-    collide_wheel(P, st, F, u, S.w, S.ww, zT, 2, true);
+    const Floor64 G = floor64(P, S);
+    collide_wheel(P, st, F, u, S.w, S.ww, zT, 1, false, G);
+    collide_wheel(P, st, F, u, S.w, S.ww, zT, 2, false, G);
+    collide_torso(P, st, F, u, S.w, S.ww, zT, G);
+    collide_wheel(P, st, F, u, S.w, S.ww, zT, 1, true, G);
+    collide_wheel(P, st, F, u, S.w, S.ww, zT, 2, true, G);
     BRS_TOC(1);
     if constexpr (BLK) {
       BRS_TIC(2);
       BRS_MARK("begin_collide_blockfloor");
 #ifndef BRS_NO_BLOCKFLOOR
-      collide_block_floor(P, st, F, uB, S.bw, zB);
+      collide_block_floor(P, st, F, S, uB, S.bw, zB);
 #endif
       BRS_TOC(2);
     }

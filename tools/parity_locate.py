@@ -66,7 +66,8 @@ def main():
     ap.add_argument("--auto-reset", type=int, default=1)
     ap.add_argument("--teacher", choices=["hostdouble", "oracle"], default="hostdouble")
     ap.add_argument("--student", choices=["host", "gpu"], default="host")
-    ap.add_argument("--actions", choices=["random", "zero"], default="random")
+    ap.add_argument("--actions", choices=["random", "zero", "policy"], default="random",
+                    help="policy = the reference's MuJoCo-trained balance policy (tests/quant_policy.py) acting on the teacher's observations")
     ap.add_argument("--max-dump", type=int, default=40)
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_parity_outliers.json"))
     a = ap.parse_args()
@@ -83,7 +84,14 @@ def main():
         S = BatchedSim(a.env, n, device=0, seed=0, auto_reset=ar, obs_noise=False)
     else:
         S = HostSim(a.env, n, seed=0, auto_reset=ar, noise=False, double=False, threads=thr)
-    T.reset(); S.reset()
+    obs_t = T.reset(); S.reset()
+    pol = None
+    if a.actions == "policy":
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import torch as _torch
+        from quant_policy import QuantMovePolicy
+        _qp = QuantMovePolicy()
+        pol = lambda o: _qp.act(_torch.from_numpy(np.ascontiguousarray(o, dtype=np.float32)), "mean").numpy()
     rng = np.random.default_rng(1234)
     outl, nsteps, over, excl, worst = [], 0, 0, 0, 0.0
     upright_over, upright_n = 0, 0
@@ -95,12 +103,16 @@ def main():
         qpos, qvel, warm, tm = T.get_state()
         aux = T.get_aux(); xq, xp = T.get_xpose()
         S.set_state(qpos, qvel, warm, tm); S.set_aux(aux); S.set_xpose(xq, xp)
-        act = np.zeros((n, 2), np.float32) if a.actions == "zero" else rng.uniform(-1, 1, size=(n, 2)).astype(np.float32)
+        if pol is not None:
+            act = pol(obs_t)
+        else:
+            act = np.zeros((n, 2), np.float32) if a.actions == "zero" else rng.uniform(-1, 1, size=(n, 2)).astype(np.float32)
         if a.student == "gpu":
             og = [x.cpu().numpy().copy() for x in S.step(torch.from_numpy(act).cuda())]
         else:
             og = S.step(act)
         ot = T.step(act)
+        obs_t = ot[0]
         qs = S.get_state()[0]; qt = T.get_state()[0]
         skip = np.zeros(n, bool)
         if ar:  # finished episodes were re-drawn; a block removed / re-thrown on one side only is a discrete difference

@@ -4,7 +4,7 @@ in DESIGN.md 2.1 and write profiles/r02_parity_report.json; exits non-zero if an
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rep, unexplained = {}, 0
-for cfg in ("config2", "config3", "config3_noreset", "config3_large"):
+for cfg in ("config2", "config3", "config3_noreset", "config3_large", "config3_policy"):
     path = os.path.join(ROOT, "profiles", f"r02_parity_{cfg}.json")
     if not os.path.exists(path):
         continue
