@@ -714,10 +714,17 @@ template <typename R, bool BLK> struct Sim {
       R bestF = (R)-1e30, bestE = (R)-1e30;
       int axF = 0, axE = -1;
       bool sep = false;
+#if defined(BRS_PATCH_DIST32)
+      const R sat_margin = c.margin;
+#else
+      // within a micrometre of the margin the fp32 axis test does not get to say "separated": the candidates' distances,
+      // taken from the fp64 poses below, decide (face axes: the deepest vertex distance IS the axis separation)
+      const R sat_margin = c.margin + (sizeof(R) == 4 ? (R)1e-6 : (R)0);
+#endif
 #pragma unroll
       for (int k = 0; k < 3; k++) {
         R sp = abs_(cg[k]) - sT[k] - s * (Q[3 * k] + Q[3 * k + 1] + Q[3 * k + 2]);
-        sep = sep | (sp > c.margin);
+        sep = sep | (sp > sat_margin);
         const bool better = sp > bestF;
         bestF = better ? sp : bestF; axF = better ? k : axF;
       }
@@ -725,7 +732,7 @@ template <typename R, bool BLK> struct Sim {
       for (int j = 0; j < 3; j++) {
         R dB = cg[0] * RTB[j] + cg[1] * RTB[3 + j] + cg[2] * RTB[6 + j];
         R sp = abs_(dB) - s - (sT[0] * Q[j] + sT[1] * Q[3 + j] + sT[2] * Q[6 + j]);
-        sep = sep | (sp > c.margin);
+        sep = sep | (sp > sat_margin);
         const bool better = sp > bestF;
         bestF = better ? sp : bestF; axF = better ? 3 + j : axF;
       }
@@ -739,7 +746,7 @@ template <typename R, bool BLK> struct Sim {
           R rT = sT[i1] * Q[3 * i2 + j] + sT[i2] * Q[3 * i1 + j], rB = s * (Q[3 * i + j1] + Q[3 * i + j2]);
           R sp = (abs_(cl) - rT - rB) * rsqrt_(max_(len2, (R)1e-12));
           const bool ok = len2 >= (R)1e-6;
-          sep = sep | (ok & (sp > c.margin));
+          sep = sep | (ok & (sp > sat_margin));
           const bool better = ok & (sp > bestE);
           bestE = better ? sp : bestE; axE = better ? 3 * i + j : axE;
         }
@@ -791,6 +798,52 @@ template <typename R, bool BLK> struct Sim {
           // candidate (u, v, g) maps back to the torso geom frame as  pos = u A1 + v A2 + (half + g/2) A3 + A0.
           BRS_MARK("cc_face_setup");
           R Cc[3], H1[3], H2[3], A0[3], A1[3], A2[3], A3[3], nrm[3], ra, rb, half;
+#if !defined(BRS_PATCH_DIST32)
+          // The NORMAL components of the incident face (centre and half edges along the reference normal) once more, from
+          // the fp64 poses: every candidate's signed distance g is affine in these three numbers, and g < margin decides
+          // whether a patch point exists in this substep -- in fp32 its rounding (~1e-8 m) put points of the patch one
+          // substep apart from the fp64 oracle (the block-quaternion outliers of DESIGN.md 2.1).  ~120 fp64 operations.
+          double Cc2, H12, H22;
+          {
+            double qT[4] = {S.q[0], S.q[1], S.q[2], S.q[3]}, qB[4] = {S.bq[0], S.bq[1], S.bq[2], S.bq[3]}, T64[9], B64[9];
+            quat2mat_(qT, T64); quat2mat_(qB, B64);
+            const double d64[3] = {S.bp[0] - S.p[0], S.bp[1] - S.p[1], S.bp[2] - S.p[2]};
+            const double cz = (double)P.torso_cz, sd = (double)s;
+            if (axF < 3) {
+              const int k = axF;
+              const double ck[3] = {pick3(k, T64[0], T64[1], T64[2]), pick3(k, T64[3], T64[4], T64[5]), pick3(k, T64[6], T64[7], T64[8])};  // column k of RT
+              const double rk[3] = {ck[0] * B64[0] + ck[1] * B64[3] + ck[2] * B64[6], ck[0] * B64[1] + ck[1] * B64[4] + ck[2] * B64[7],
+                                    ck[0] * B64[2] + ck[1] * B64[5] + ck[2] * B64[8]};  // row k of RTB
+              const double cgk = ck[0] * d64[0] + ck[1] * d64[1] + ck[2] * d64[2] - (k == 2 ? cz : 0.0);
+              const double sg = pick3(k, cg) >= 0 ? 1.0 : -1.0;
+              int js = 0;  // (same discrete choices as the fp32 code below, made on the fp32 values)
+              {
+                const R r0 = pick3(k, RTB[0], RTB[3], RTB[6]), r1 = pick3(k, RTB[1], RTB[4], RTB[7]), r2 = pick3(k, RTB[2], RTB[5], RTB[8]);
+                if (abs_(r1) > abs_(r0)) js = 1;
+                if (abs_(r2) > abs_(pick3(js, r0, r1, r2))) js = 2;
+                const double sj = -sg * (pick3(js, r0, r1, r2) >= 0 ? 1.0 : -1.0);
+                const int a1 = js == 2 ? 0 : js + 1, a2 = js == 0 ? 2 : js - 1;
+                Cc2 = sg * (cgk + sj * sd * pick3(js, rk)) - (double)pick3(k, sT);
+                H12 = sg * sd * pick3(a1, rk); H22 = sg * sd * pick3(a2, rk);
+              }
+            } else {
+              const int j = axF - 3;
+              const double cj[3] = {pick3(j, B64[0], B64[1], B64[2]), pick3(j, B64[3], B64[4], B64[5]), pick3(j, B64[6], B64[7], B64[8])};  // block axis j, world
+              const double bj64[3] = {T64[0] * cj[0] + T64[3] * cj[1] + T64[6] * cj[2], T64[1] * cj[0] + T64[4] * cj[1] + T64[7] * cj[2],
+                                      T64[2] * cj[0] + T64[5] * cj[1] + T64[8] * cj[2]};  // the same axis in the torso frame
+              const double dotbc = cj[0] * d64[0] + cj[1] * d64[1] + cj[2] * d64[2] - bj64[2] * cz;  // bj . cg
+              const R bjf[3] = {pick3(j, RTB[0], RTB[1], RTB[2]), pick3(j, RTB[3], RTB[4], RTB[5]), pick3(j, RTB[6], RTB[7], RTB[8])};
+              const double sgB = dot_(cg, bjf) >= 0 ? 1.0 : -1.0;
+              int ks = 0;
+              if (abs_(bjf[1]) > abs_(bjf[0])) ks = 1;
+              if (abs_(bjf[2]) > abs_(pick3(ks, bjf))) ks = 2;
+              const double sk = sgB * (pick3(ks, bjf) >= 0 ? 1.0 : -1.0);
+              const int a1 = ks == 2 ? 0 : ks + 1, a2 = ks == 0 ? 2 : ks - 1;
+              Cc2 = -sgB * (sk * (double)pick3(ks, sT) * pick3(ks, bj64) - dotbc) - sd;
+              H12 = -sgB * (double)pick3(a1, sT) * pick3(a1, bj64); H22 = -sgB * (double)pick3(a2, sT) * pick3(a2, bj64);
+            }
+          }
+#endif
           if (axF < 3) {
             const int k = axF, j1 = k == 2 ? 0 : k + 1, j2 = k == 0 ? 2 : k - 1;
             const R sg = pick3(k, cg) >= 0 ? (R)1 : (R)-1;
@@ -850,16 +903,25 @@ template <typename R, bool BLK> struct Sim {
           R cu_[16], cv_[16], gq[16];
           uint32_t vmask = 0;
           bool ins[4];
+#if defined(BRS_PATCH_DIST32)
+          typedef R GT;
+          const GT Vg[4] = {V[0][2], V[1][2], V[2][2], V[3][2]}, H12x2 = 2 * H1[2], H22x2 = 2 * H2[2];
+#else
+          typedef double GT;
+          const GT Vg[4] = {Cc2 - H12 - H22, Cc2 + H12 - H22, Cc2 + H12 + H22, Cc2 - H12 + H22}, H12x2 = 2 * H12, H22x2 = 2 * H22;
+#endif
+          const GT gmargin = (GT)c.margin;
 #pragma unroll
           for (int v = 0; v < 4; v++) {
             ins[v] = (abs_(V[v][0]) <= ra) & (abs_(V[v][1]) <= rb);
-            vmask |= (ins[v] & (V[v][2] < c.margin)) ? (1u << v) : 0u;
-            cu_[v] = V[v][0]; cv_[v] = V[v][1]; gq[v] = V[v][2];
+            vmask |= (ins[v] & (Vg[v] < gmargin)) ? (1u << v) : 0u;
+            cu_[v] = V[v][0]; cv_[v] = V[v][1]; gq[v] = (R)Vg[v];
           }
 #pragma unroll
           for (int e = 0; e < 4; e++) {
             const int e1 = (e + 1) & 3;
-            const R du = V[e1][0] - V[e][0], dv = V[e1][1] - V[e][1], dg = V[e1][2] - V[e][2];
+            const R du = V[e1][0] - V[e][0], dv = V[e1][1] - V[e][1];
+            const GT dg = Vg[e1] - Vg[e];
             // Liang-Barsky against |u| <= ra, |v| <= rb
             R t0 = 0, t1 = 1;
             bool ok = true;
@@ -876,11 +938,11 @@ template <typename R, bool BLK> struct Sim {
               t1 = (!zero & (pp[b4] > 0) & (r < t1)) ? r : t1;
             }
             ok = ok & (t0 < t1);
-            const R g0 = V[e][2] + t0 * dg, g1 = V[e][2] + t1 * dg;
-            vmask |= (ok & !ins[e] & (g0 < c.margin)) ? (1u << (4 + 2 * e)) : 0u;
-            vmask |= (ok & !ins[e1] & (g1 < c.margin)) ? (1u << (5 + 2 * e)) : 0u;
-            cu_[4 + 2 * e] = V[e][0] + t0 * du; cv_[4 + 2 * e] = V[e][1] + t0 * dv; gq[4 + 2 * e] = g0;
-            cu_[5 + 2 * e] = V[e][0] + t1 * du; cv_[5 + 2 * e] = V[e][1] + t1 * dv; gq[5 + 2 * e] = g1;
+            const GT g0 = Vg[e] + (GT)t0 * dg, g1 = Vg[e] + (GT)t1 * dg;
+            vmask |= (ok & !ins[e] & (g0 < gmargin)) ? (1u << (4 + 2 * e)) : 0u;
+            vmask |= (ok & !ins[e1] & (g1 < gmargin)) ? (1u << (5 + 2 * e)) : 0u;
+            cu_[4 + 2 * e] = V[e][0] + t0 * du; cv_[4 + 2 * e] = V[e][1] + t0 * dv; gq[4 + 2 * e] = (R)g0;
+            cu_[5 + 2 * e] = V[e][0] + t1 * du; cv_[5 + 2 * e] = V[e][1] + t1 * dv; gq[5 + 2 * e] = (R)g1;
           }
           {  // rectangle corners inside the incident parallelogram: corner = V0 + al (V1 - V0) + be (V3 - V0)
             const R e1u = 2 * H1[0], e1v = 2 * H1[1], e2u = 2 * H2[0], e2v = 2 * H2[1];
@@ -891,10 +953,10 @@ template <typename R, bool BLK> struct Sim {
             for (int q = 0; q < 4; q++) {
               const R cu = (q & 1) ? ra : -ra, cv = (q & 2) ? rb : -rb, ru = cu - V[0][0], rv = cv - V[0][1];
               const R al = (ru * e2v - rv * e2u) * idet, be = (e1u * rv - e1v * ru) * idet;
-              const R g = V[0][2] + al * (2 * H1[2]) + be * (2 * H2[2]);
+              const GT g = Vg[0] + (GT)al * H12x2 + (GT)be * H22x2;
               const bool in = dok & (al > 0) & (al < 1) & (be > 0) & (be < 1);
-              vmask |= (in & (g < c.margin)) ? (1u << (12 + q)) : 0u;
-              cu_[12 + q] = cu; cv_[12 + q] = cv; gq[12 + q] = g;
+              vmask |= (in & (g < gmargin)) ? (1u << (12 + q)) : 0u;
+              cu_[12 + q] = cu; cv_[12 + q] = cv; gq[12 + q] = (R)g;
             }
           }
           BRS_MARK("cc_reduce");
