@@ -116,3 +116,31 @@ def test_mujoco_trained_policy_balances_the_hip_path():
             assert np.median(err) < 0.06 and np.quantile(err, 0.99) < 0.15, f"{mode}: step {e}: median {np.median(err):.3f} p99 {np.quantile(err, 0.99):.3f}"
             assert P[20 * j:20 * j + 20].max(axis=0)[alive].max() < 0.3
         sim.close(); pol.close()
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/src/balance_robot/envs/RobotMovePolicy.tflite"),
+                    reason="the reference checkout is only present in the build container")
+def test_fixture_regenerates_from_the_reference_file():
+    """tools/gen_policy_fixture.py run again on the reference's .tflite gives the committed arrays (nothing hand-edited)"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from tflite_reader import read_tflite
+    m = read_tflite("/root/reference/src/balance_robot/envs/RobotMovePolicy.tflite")
+    z = np.load(os.path.join(ROOT, "tests", "golden", "robot_move_policy.npz"))
+    T = m["tensors"]
+    ops = {o["outputs"][0]: o for o in m["operators"]}
+    # walk output[1] (the actions the reference reads) back to the input
+    t, fcs = m["outputs"][1], []
+    while t != m["inputs"][0]:
+        o = ops[t]
+        if o["op"] == "FULLY_CONNECTED":
+            fcs.append(o)
+        t = o["inputs"][0]
+    fcs.reverse()
+    assert len(fcs) == 3
+    for k, o in enumerate(fcs):
+        np.testing.assert_array_equal(z[f"fc{k}_weight_q"], T[o["inputs"][1]]["data"])
+        np.testing.assert_array_equal(z[f"fc{k}_bias_q"], T[o["inputs"][2]]["data"])
+        np.testing.assert_allclose(z[f"fc{k}_weight_scale"], np.asarray(T[o["inputs"][1]]["scale"], np.float64))
+        np.testing.assert_allclose(z[f"fc{k}_out_scale"], np.asarray(T[o["outputs"][0]]["scale"], np.float64))
+    np.testing.assert_allclose(z["input_scale"], np.asarray(T[m["inputs"][0]]["scale"], np.float64))
+    assert int(z["input_zero_point"][0]) == T[m["inputs"][0]]["zero_point"][0]
