@@ -65,6 +65,11 @@ __device__ __forceinline__ unsigned long long* brs_tim_slots() {  // 16 x u64 pe
 #ifndef BRS_UNDAMPED_ITERS
 #define BRS_UNDAMPED_ITERS 3
 #endif
+// velocities carried as fp64 ACCUMULATORS (like qpos and time): the state enters a step with the caller's fp64 qvel, h * acc is
+// added in fp64 and the fp32 copy the force path reads is re-derived from it every substep
+#ifndef BRS_VEL64
+#define BRS_VEL64 1
+#endif
 
 namespace brs {
 
@@ -112,6 +117,17 @@ BRS_HD double sqrt64_(double s) {
   return s * y;
 #else
   return sqrt(s);
+#endif
+}
+// 1/sqrt of a double in [1e-6, 1] the same way
+BRS_HD double rsqrt64_(double s) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = (double)__builtin_amdgcn_rsqf((float)s);
+  y = y * (1.5 - 0.5 * s * y * y);
+  y = y * (1.5 - 0.5 * s * y * y);
+  return y;
+#else
+  return 1.0 / sqrt(s);
 #endif
 }
 BRS_HD float abs_(float x) { return fabsf(x); }
@@ -260,6 +276,16 @@ template <typename R, bool BLK> struct EnvState {
   R v[3], w[3], ww[2];       // world-frame linear velocity, BODY-frame angular velocity, wheel rates
   double bp[3], bq[4];       // block pose
   R bv[3], bw[3];            // block: world linear, body angular
+#if BRS_VEL64
+  double vd[3], wd[3], wwd[2], bvd[3], bwd[3];  // the fp64 accumulators behind v, w, ww, bv, bw (those are their roundings)
+#endif
+  BRS_HD void sync_vel64() {  // after code that wrote the fp32 velocities directly (reset, block throw)
+#if BRS_VEL64
+    for (int i = 0; i < 3; i++) { vd[i] = (double)v[i]; wd[i] = (double)w[i]; }
+    wwd[0] = (double)ww[0]; wwd[1] = (double)ww[1];
+    if constexpr (BLK) { for (int i = 0; i < 3; i++) { bvd[i] = (double)bv[i]; bwd[i] = (double)bw[i]; } }
+#endif
+  }
   R a[NV];                   // solver variable / warm start, BODY-frame linear coordinates (robot and block)
   double time;
   // accessor pose: what data.body("robot_body").xquat/.xpos would read (kinematics of the last forward pass)
@@ -277,6 +303,13 @@ template <typename R, bool BLK> struct EnvState {
   int pnfr, pnfb, pnc;  // previous substep: contact-list lengths, body selectors and final active-row masks -- the first
   uint32_t psels, pmR, pmB, pmC;  // guess of this substep's active set (not persisted across launches)
 };
+
+// type of the two servo targets (data.ctrl) held across the substeps of a step: the reference forms ctrl = qvel + 4 a in fp64
+#if BRS_VEL64
+template <typename R> using CtrlT = double;
+#else
+template <typename R> using CtrlT = R;
+#endif
 
 template <typename R> BRS_HD R impedance_(const ContactClass<R>& c, R dist) {
   if (c.inv_width == (R)0) return c.d0;
@@ -524,10 +557,11 @@ template <typename R, bool BLK> struct Sim {
     const R d1 = dist0 + prjaxis + prjvec, d2 = dist0 - prjaxis + prjvec, dT = dist0 + prjaxis - (R)0.5 * prjvec;
     const bool in1 = d1 < c.margin, in2 = d2 < c.margin, inT = dT < c.margin;
 #else
-    const double prjaxis = -abs_(G.nx) * (double)P.wheel_hl, prjvec = -(double)P.wheel_r * G.len;  // vy ny + vz nz = -r len
-    const double dist0 = G.zT + G.nx * (double)px + G.nz * (double)pz;
+    const double prjaxis = -abs_(G.nx) * P.wheel_hl_d, prjvec = -P.wheel_r_d * G.len;  // vy ny + vz nz = -r len
+    const double dist0 = G.zT + G.nx * (sel == 1 ? -P.wheel_px_d : P.wheel_px_d) + G.nz * P.wheel_pz_d;
     const double d1d = dist0 + prjaxis + prjvec, d2d = dist0 - prjaxis + prjvec, dTd = dist0 + prjaxis - 0.5 * prjvec;
-    const bool in1 = d1d < (double)c.margin, in2 = d2d < (double)c.margin, inT = dTd < (double)c.margin;
+    const double mg = P.margin_d[CC_WHEEL_FLOOR];
+    const bool in1 = d1d < mg, in2 = d2d < mg, inT = dTd < mg;
     const R d1 = (R)d1d, d2 = (R)d2d, dT = (R)dTd;
 #endif
     if (!in1) return;
@@ -574,12 +608,13 @@ template <typename R, bool BLK> struct Sim {
     // cheap reject: lowest corner
     R low = dc - (abs_(nx) * P.torso_sx + abs_(ny) * P.torso_sy + abs_(nz) * P.torso_sz);
     if (!(low < c.margin + (R)1e-6)) return;  // (fp32 reject with slack; the decisions below are made in fp64)
-    const double dcd = G.zT + G.nz * (double)P.torso_cz;
-    int list, cnt = box_corners<double>(G.nx, G.ny, G.nz, (double)P.torso_sx, (double)P.torso_sy, (double)P.torso_sz, dcd, (double)c.margin, list);
+    const double dcd = G.zT + G.nz * P.torso_cz_d;
+    int list, cnt = box_corners<double>(G.nx, G.ny, G.nz, P.torso_s_d[0], P.torso_s_d[1], P.torso_s_d[2], dcd, P.margin_d[CC_TORSO_FLOOR], list);
     for (int k = 0; k < cnt; k++) {
       int i = (list >> (3 * k)) & 7;
       R lx = (i & 1) ? P.torso_sx : -P.torso_sx, ly = (i & 2) ? P.torso_sy : -P.torso_sy, lz = (i & 4) ? P.torso_sz : -P.torso_sz;
-      R d = (R)(dcd + G.nx * (double)lx + G.ny * (double)ly + G.nz * (double)lz);
+      R d = (R)(dcd + G.nx * ((i & 1) ? P.torso_s_d[0] : -P.torso_s_d[0]) + G.ny * ((i & 2) ? P.torso_s_d[1] : -P.torso_s_d[1]) +
+                G.nz * ((i & 4) ? P.torso_s_d[2] : -P.torso_s_d[2]));
       R pt[3] = {lx, ly, P.torso_cz + lz};
       add_robot_floor(P, st, F, u, w, ww, 0, CC_TORSO_FLOOR, pt, d);
     }
@@ -591,12 +626,12 @@ template <typename R, bool BLK> struct Sim {
     if (!(low < c.margin + (R)1e-6)) return;  // (fp32 reject with slack; the decisions below are made in fp64, see Floor64)
     const double qw = S.bq[0], qx = S.bq[1], qy = S.bq[2], qz = S.bq[3];
     const double nxd = 2 * (qx * qz - qw * qy), nyd = 2 * (qy * qz + qw * qx), nzd = 1 - 2 * (qx * qx + qy * qy);
-    const double zBd = S.bp[2] - P.floor_z_d, sd = (double)s;
-    int list, cnt = box_corners<double>(nxd, nyd, nzd, sd, sd, sd, zBd, (double)c.margin, list);
+    const double zBd = S.bp[2] - P.floor_z_d, sd = P.block_s_d;
+    int list, cnt = box_corners<double>(nxd, nyd, nzd, sd, sd, sd, zBd, P.margin_d[CC_BLOCK_FLOOR], list);
     for (int k = 0; k < cnt; k++) {
       int i = (list >> (3 * k)) & 7;
       R lx = (i & 1) ? s : -s, ly = (i & 2) ? s : -s, lz = (i & 4) ? s : -s;
-      R d = (R)(zBd + nxd * (double)lx + nyd * (double)ly + nzd * (double)lz);
+      R d = (R)(zBd + nxd * ((i & 1) ? sd : -sd) + nyd * ((i & 2) ? sd : -sd) + nzd * ((i & 4) ? sd : -sd));
       R r[3] = {lx - nx * d * (R)0.5, ly - ny * d * (R)0.5, lz - nz * d * (R)0.5};
       R wr[3];
       cross_(wB, r, wr);
@@ -712,6 +747,7 @@ template <typename R, bool BLK> struct Sim {
 #pragma unroll
       for (int i = 0; i < 9; i++) Q[i] = abs_(RTB[i]);
       R bestF = (R)-1e30, bestE = (R)-1e30;
+      double bestE64 = 0;
       int axF = 0, axE = -1;
       bool sep = false;
 #if defined(BRS_PATCH_DIST32)
@@ -755,9 +791,34 @@ template <typename R, bool BLK> struct Sim {
         BRS_MARK("cc_branch");
         const bool use_edge = (axE >= 0) & (bestE > bestF + (R)0.05 * abs_(bestF) + (R)1e-5);
         if (use_edge) {
-          if (bestE < c.margin) {
-            const int i = axE / 3, j = axE - 3 * i;
-            const int i1 = i == 2 ? 0 : i + 1, i2 = i == 0 ? 2 : i - 1;
+          const int i = axE / 3, j = axE - 3 * i;
+          const int i1 = i == 2 ? 0 : i + 1, i2 = i == 0 ? 2 : i - 1;
+#if defined(BRS_PATCH_DIST32)
+          const bool edge_in = bestE < c.margin;
+#else
+          // the separation along the chosen edge axis L = e_i x b_j once more from the fp64 poses: it is the distance of the
+          // patch's only point, and `< margin` decides whether that point exists in this substep (like the face case below;
+          // the axis itself is the fp32 choice).  ~90 fp64 operations, only for lanes in the edge case.
+          {
+            double qT[4] = {S.q[0], S.q[1], S.q[2], S.q[3]}, qB[4] = {S.bq[0], S.bq[1], S.bq[2], S.bq[3]}, T64[9], B64[9];
+            quat2mat_(qT, T64); quat2mat_(qB, B64);
+            const double d64[3] = {S.bp[0] - S.p[0], S.bp[1] - S.p[1], S.bp[2] - S.p[2]};
+            const int j1 = j == 2 ? 0 : j + 1, j2 = j == 0 ? 2 : j - 1;
+            auto colT = [&](int a, double* o) { o[0] = pick3(a, T64[0], T64[1], T64[2]); o[1] = pick3(a, T64[3], T64[4], T64[5]); o[2] = pick3(a, T64[6], T64[7], T64[8]); };
+            auto colB = [&](int a, double* o) { o[0] = pick3(a, B64[0], B64[1], B64[2]); o[1] = pick3(a, B64[3], B64[4], B64[5]); o[2] = pick3(a, B64[6], B64[7], B64[8]); };
+            double ti[3], ti1[3], ti2[3], bjw[3], bj1w[3], bj2w[3];
+            colT(i, ti); colT(i1, ti1); colT(i2, ti2); colB(j, bjw); colB(j1, bj1w); colB(j2, bj2w);
+            const double Rij = dot_(ti, bjw), Ri1j = dot_(ti1, bjw), Ri2j = dot_(ti2, bjw), Rij1 = dot_(ti, bj1w), Rij2 = dot_(ti, bj2w);
+            const double cgi1 = dot_(ti1, d64) - (i1 == 2 ? P.torso_cz_d : 0.0), cgi2 = dot_(ti2, d64) - (i2 == 2 ? P.torso_cz_d : 0.0);
+            const double cl = cgi2 * Ri1j - cgi1 * Ri2j;
+            const double rT64 = pick3(i1, P.torso_s_d) * abs_(Ri2j) + pick3(i2, P.torso_s_d) * abs_(Ri1j), rB64 = P.block_s_d * (abs_(Rij1) + abs_(Rij2));
+            const double len2 = 1.0 - Rij * Rij;  // >= 1e-6: the axis passed the fp32 parallel test
+            bestE64 = (abs_(cl) - rT64 - rB64) * rsqrt64_(len2);
+          }
+          const bool edge_in = bestE64 < P.margin_d[CC_BLOCK_ROBOT];
+          bestE = (R)bestE64;
+#endif
+          if (edge_in) {
             R bj[3] = {pick3(j, RTB[0], RTB[1], RTB[2]), pick3(j, RTB[3], RTB[4], RTB[5]), pick3(j, RTB[6], RTB[7], RTB[8])};
             const R bji = pick3(i, bj), bji1 = pick3(i1, bj), bji2 = pick3(i2, bj);
             R il = rsqrt_((R)1 - bji * bji);
@@ -808,7 +869,8 @@ template <typename R, bool BLK> struct Sim {
             double qT[4] = {S.q[0], S.q[1], S.q[2], S.q[3]}, qB[4] = {S.bq[0], S.bq[1], S.bq[2], S.bq[3]}, T64[9], B64[9];
             quat2mat_(qT, T64); quat2mat_(qB, B64);
             const double d64[3] = {S.bp[0] - S.p[0], S.bp[1] - S.p[1], S.bp[2] - S.p[2]};
-            const double cz = (double)P.torso_cz, sd = (double)s;
+            const double cz = P.torso_cz_d, sd = P.block_s_d;
+            const double sTd[3] = {P.torso_s_d[0], P.torso_s_d[1], P.torso_s_d[2]};
             if (axF < 3) {
               const int k = axF;
               const double ck[3] = {pick3(k, T64[0], T64[1], T64[2]), pick3(k, T64[3], T64[4], T64[5]), pick3(k, T64[6], T64[7], T64[8])};  // column k of RT
@@ -823,7 +885,7 @@ template <typename R, bool BLK> struct Sim {
                 if (abs_(r2) > abs_(pick3(js, r0, r1, r2))) js = 2;
                 const double sj = -sg * (pick3(js, r0, r1, r2) >= 0 ? 1.0 : -1.0);
                 const int a1 = js == 2 ? 0 : js + 1, a2 = js == 0 ? 2 : js - 1;
-                Cc2 = sg * (cgk + sj * sd * pick3(js, rk)) - (double)pick3(k, sT);
+                Cc2 = sg * (cgk + sj * sd * pick3(js, rk)) - pick3(k, sTd);
                 H12 = sg * sd * pick3(a1, rk); H22 = sg * sd * pick3(a2, rk);
               }
             } else {
@@ -839,8 +901,8 @@ template <typename R, bool BLK> struct Sim {
               if (abs_(bjf[2]) > abs_(pick3(ks, bjf))) ks = 2;
               const double sk = sgB * (pick3(ks, bjf) >= 0 ? 1.0 : -1.0);
               const int a1 = ks == 2 ? 0 : ks + 1, a2 = ks == 0 ? 2 : ks - 1;
-              Cc2 = -sgB * (sk * (double)pick3(ks, sT) * pick3(ks, bj64) - dotbc) - sd;
-              H12 = -sgB * (double)pick3(a1, sT) * pick3(a1, bj64); H22 = -sgB * (double)pick3(a2, sT) * pick3(a2, bj64);
+              Cc2 = -sgB * (sk * pick3(ks, sTd) * pick3(ks, bj64) - dotbc) - sd;
+              H12 = -sgB * pick3(a1, sTd) * pick3(a1, bj64); H22 = -sgB * pick3(a2, sTd) * pick3(a2, bj64);
             }
           }
 #endif
@@ -910,7 +972,11 @@ template <typename R, bool BLK> struct Sim {
           typedef double GT;
           const GT Vg[4] = {Cc2 - H12 - H22, Cc2 + H12 - H22, Cc2 + H12 + H22, Cc2 - H12 + H22}, H12x2 = 2 * H12, H22x2 = 2 * H22;
 #endif
+#if defined(BRS_PATCH_DIST32)
           const GT gmargin = (GT)c.margin;
+#else
+          const GT gmargin = P.margin_d[CC_BLOCK_ROBOT];
+#endif
 #pragma unroll
           for (int v = 0; v < 4; v++) {
             ins[v] = (abs_(V[v][0]) <= ra) & (abs_(V[v][1]) <= rb);
@@ -1540,7 +1606,8 @@ template <typename R, bool BLK> struct Sim {
     int it;
     Masks M;
   };
-  static BRS_HD void sub_begin(const Params<R>& P, Store<R>& st, ES& S, R ctrlL, R ctrlR, SubCtx& C) {
+  using CT = CtrlT<R>;
+  static BRS_HD void sub_begin(const Params<R>& P, Store<R>& st, ES& S, CT ctrlL, CT ctrlR, SubCtx& C) {
     Frame& F = C.F;
     R* f = C.f;
     BRS_MARK("begin_kin");
@@ -1562,12 +1629,23 @@ template <typename R, bool BLK> struct Sim {
     f[4] = -(wz * Lx - wx * Lz) + P.mcz * gb[0];
     f[5] = -(wx * Ly - wy * Lx);
     // velocity servos (envs/robot-02.xml:22-25): ctrl clamp, force clamp; derivative dropped when clamped
+#if BRS_VEL64
+    // target minus wheel rate in fp64: the two are close (ctrl = rate + 4 a), their fp32 difference would carry ~1e-5 of the force,
+    // and whether the force clamp binds -- which decides if the servo's derivative enters implicitfast -- is a discrete
+    // outcome: a wheel gains 0.26 rad/s per substep clamped and 0.10 unclamped
+    const double uLd = min_(max_(ctrlL, -P.ctrlrange_d), P.ctrlrange_d), uRd = min_(max_(ctrlR, -P.ctrlrange_d), P.ctrlrange_d);
+    const double fLd = P.kv_d * (uLd - S.wwd[0]), fRd = P.kv_d * (uRd - S.wwd[1]);
+    C.clL = fLd >= P.forcerange_d || fLd <= -P.forcerange_d;
+    C.clR = fRd >= P.forcerange_d || fRd <= -P.forcerange_d;
+    R fL = (R)min_(max_(fLd, -P.forcerange_d), P.forcerange_d), fR = (R)min_(max_(fRd, -P.forcerange_d), P.forcerange_d);
+#else
     R uL = min_(max_(ctrlL, -P.ctrlrange), P.ctrlrange), uR = min_(max_(ctrlR, -P.ctrlrange), P.ctrlrange);
     R fL = P.kv * (uL - S.ww[0]), fR = P.kv * (uR - S.ww[1]);
     C.clL = fL >= P.forcerange || fL <= -P.forcerange;
     C.clR = fR >= P.forcerange || fR <= -P.forcerange;
     fL = min_(max_(fL, -P.forcerange), P.forcerange);
     fR = min_(max_(fR, -P.forcerange), P.forcerange);
+#endif
     f[6] = fL - P.damping * S.ww[0];
     f[7] = fR - P.damping * S.ww[1];
     msolve0_(P, f, F.a0);
@@ -1647,6 +1725,20 @@ template <typename R, bool BLK> struct Sim {
     // advance: velocities first, then positions with the NEW velocities
     R aw[3];
     mul_(F.RT, acc, aw);
+#if BRS_VEL64
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      S.vd[i] += P.h_d * (double)aw[i]; S.wd[i] += P.h_d * (double)acc[3 + i];
+      S.v[i] = (R)S.vd[i]; S.w[i] = (R)S.wd[i];
+    }
+    S.wwd[0] += P.h_d * (double)acc[6]; S.wwd[1] += P.h_d * (double)acc[7];
+    S.ww[0] = (R)S.wwd[0]; S.ww[1] = (R)S.wwd[1];
+#pragma unroll
+    for (int i = 0; i < 3; i++) S.p[i] += P.h_d * S.vd[i];
+    quat_advance(S.q, S.wd[0], S.wd[1], S.wd[2], P.h_d);
+    S.th[0] += P.h_d * S.wwd[0];
+    S.th[1] += P.h_d * S.wwd[1];
+#else
 #pragma unroll
     for (int i = 0; i < 3; i++) { S.v[i] += P.h * aw[i]; S.w[i] += P.h * acc[3 + i]; }
     S.ww[0] += P.h * acc[6];
@@ -1656,15 +1748,27 @@ template <typename R, bool BLK> struct Sim {
     quat_advance(S.q, (double)S.w[0], (double)S.w[1], (double)S.w[2], P.h_d);
     S.th[0] += P.h_d * (double)S.ww[0];
     S.th[1] += P.h_d * (double)S.ww[1];
+#endif
     if constexpr (BLK) {
       // block smooth force: gravity only (isotropic inertia: no gyroscopic torque)
       R ab[3], al[3] = {fcon[8] * P.inv_mB - P.g * F.nB()[0], fcon[9] * P.inv_mB - P.g * F.nB()[1], fcon[10] * P.inv_mB - P.g * F.nB()[2]};
       mul_(F.RB, al, ab);
+#if BRS_VEL64
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        S.bvd[i] += P.h_d * (double)ab[i]; S.bwd[i] += P.h_d * (double)(fcon[11 + i] * P.inv_IB);
+        S.bv[i] = (R)S.bvd[i]; S.bw[i] = (R)S.bwd[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 3; i++) S.bp[i] += P.h_d * S.bvd[i];
+      quat_advance(S.bq, S.bwd[0], S.bwd[1], S.bwd[2], P.h_d);
+#else
 #pragma unroll
       for (int i = 0; i < 3; i++) { S.bv[i] += P.h * ab[i]; S.bw[i] += P.h * fcon[11 + i] * P.inv_IB; }
 #pragma unroll
       for (int i = 0; i < 3; i++) S.bp[i] += P.h_d * (double)S.bv[i];
       quat_advance(S.bq, (double)S.bw[0], (double)S.bw[1], (double)S.bw[2], P.h_d);
+#endif
     }
     S.time += P.h_d;
     // first guess of the next substep's active set
@@ -1677,7 +1781,7 @@ template <typename R, bool BLK> struct Sim {
     BRS_MARK("end_done");
   }
   // un-flattened form (one lane at a time: host tests, single substeps)
-  static BRS_HD void substep(const Params<R>& P, Store<R>& st, ES& S, R ctrlL, R ctrlR) {
+  static BRS_HD void substep(const Params<R>& P, Store<R>& st, ES& S, CT ctrlL, CT ctrlR) {
     SubCtx C;
     sub_begin(P, st, S, ctrlL, ctrlR, C);
     while (!C.conv) sub_iter(P, st, S, C);
@@ -1766,6 +1870,9 @@ template <typename R, bool BLK> struct Sim {
     (void)xp0; (void)xp1;
     euler_slot_quat(xr, yr, zr, S.bq);
     S.bv[0] = vx * k; S.bv[1] = vy * k; S.bv[2] = vz * k;
+#if BRS_VEL64
+    if constexpr (BLK) { S.bvd[0] = (double)S.bv[0]; S.bvd[1] = (double)S.bv[1]; S.bvd[2] = (double)S.bv[2]; }
+#endif
   }
   static BRS_HD void env_reset(const Params<R>& P, ES& S, Stream<R>& rng, float* obs) {
     const R TWO_PI = (R)6.283185307179586476925;
@@ -1797,14 +1904,16 @@ template <typename R, bool BLK> struct Sim {
     if constexpr (BLK) {
 #pragma unroll
       for (int i = 0; i < 3; i++) { S.bw[i] = 0; }
+      S.sync_vel64();
       set_block_pos_vel(P, S, rng);
       S.block_timer = -1.0;
-    }
+    } else
+      S.sync_vel64();
     get_obs(P, S, rng, true, obs);
   }
 
   // ---- one full env step = env_pre (reward + control law on the PRE-step state) -> nsub substeps -> env_post
-  static BRS_HD R env_pre(const Params<R>& P, ES& S, Stream<R>& rng, float a0, float a1, R& ctrlL, R& ctrlR) {
+  static BRS_HD R env_pre(const Params<R>& P, ES& S, Stream<R>& rng, float a0, float a1, CT& ctrlL, CT& ctrlR) {
     if (P.v3) {  // envs/env01_v3.py:28-36: schedule keyed on data.time at the start of step
       const double t = S.time;  // fp64 like the reference: the accumulated time sits within rounding of the thresholds
       if (t > 5.5) S.tws = (R)3 * S.dts;
@@ -1813,8 +1922,13 @@ template <typename R, bool BLK> struct Sim {
       else if (t > 1.0) S.tws = S.dts;
     }
     R rew = get_reward(P, S, rng);
+#if BRS_VEL64
+    ctrlL = S.wwd[0] + (double)a0 * 4.0;  // envs/env01_v2.py:31-36 ; the env does not clip the action
+    ctrlR = S.wwd[1] + (double)a1 * 4.0;
+#else
     ctrlL = S.ww[0] + (R)a0 * (R)4;  // envs/env01_v2.py:31-36 ; the env does not clip the action
     ctrlR = S.ww[1] + (R)a1 * (R)4;
+#endif
     return rew;
   }
   static BRS_HD void env_post(const Params<R>& P, ES& S, Stream<R>& rng, R rew, float* obs, float* terminal_obs, float& reward,
@@ -1851,7 +1965,7 @@ template <typename R, bool BLK> struct Sim {
   }
   static BRS_HD void env_step(const Params<R>& P, Store<R>& st, ES& S, Stream<R>& rng, float a0, float a1, float* obs,
                               float* terminal_obs, float& reward, int& terminated, int& truncated) {
-    R ctrlL, ctrlR;
+    CT ctrlL, ctrlR;
     R rew = env_pre(P, S, rng, a0, a1, ctrlL, ctrlR);
     for (int k = 0; k < P.nsub; k++) {
       if (k == P.nsub - 1) {  // accessor pose = kinematics of the LAST forward pass (lags qpos by one substep)

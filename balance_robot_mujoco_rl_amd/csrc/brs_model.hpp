@@ -45,6 +45,12 @@ struct Params {
   R torso_sx, torso_sy, torso_sz, torso_cz;
   R floor_z;
   double floor_z_d;
+  // the same geometry in fp64 for the code that DECIDES whether a contact point exists (brs_core.hpp: Floor64, collide_coupled):
+  // (double)(float)0.034 is 1.8 nm off 0.034 -- a grazing wheel moves 20 nm per substep, so that bias alone moves the substep at
+  // which its contact point switches on or off against the fp64 oracle
+  double wheel_px_d, wheel_pz_d, wheel_r_d, wheel_hl_d, torso_s_d[3], torso_cz_d, block_s_d;
+  double margin_d[CC_COUNT];
+  double kv_d, ctrlrange_d, forcerange_d;  // the servo's clamp decisions are taken in fp64 as well (brs_core.hpp: sub_begin)
   // actuators / passive
   R kv, ctrlrange, forcerange, damping;
   // block
@@ -129,7 +135,10 @@ constexpr Params<R> make_params(int variant, uint32_t flags_auto_reset, int nois
   p.wheel_px = (R)r.wheel_px; p.wheel_pz = (R)r.wheel_pz; p.wheel_r = (R)r.wheel_r; p.wheel_hl = (R)r.wheel_hl;
   p.torso_sx = (R)r.torso_s[0]; p.torso_sy = (R)r.torso_s[1]; p.torso_sz = (R)r.torso_s[2]; p.torso_cz = (R)r.torso_gz;
   p.floor_z = (R)r.floor_z; p.floor_z_d = r.floor_z;
+  p.wheel_px_d = r.wheel_px; p.wheel_pz_d = r.wheel_pz; p.wheel_r_d = r.wheel_r; p.wheel_hl_d = r.wheel_hl;
+  p.torso_s_d[0] = r.torso_s[0]; p.torso_s_d[1] = r.torso_s[1]; p.torso_s_d[2] = r.torso_s[2]; p.torso_cz_d = r.torso_gz; p.block_s_d = r.block_s;
   p.kv = (R)r.kv; p.ctrlrange = (R)r.ctrlrange; p.forcerange = (R)r.forcerange; p.damping = (R)r.damping;
+  p.kv_d = r.kv; p.ctrlrange_d = r.ctrlrange; p.forcerange_d = r.forcerange;
   double mB = 8 * r.block_s * r.block_s * r.block_s * r.density, IB = mB / 3 * 2 * r.block_s * r.block_s;
   p.mB = (R)mB; p.IB = (R)IB; p.block_s = (R)r.block_s; p.inv_mB = (R)(1 / mB); p.inv_IB = (R)(1 / IB);
   p.torso_brad = (R)csqrt(r.torso_s[0] * r.torso_s[0] + r.torso_s[1] * r.torso_s[1] + r.torso_s[2] * r.torso_s[2]);
@@ -170,6 +179,7 @@ constexpr Params<R> make_params(int variant, uint32_t flags_auto_reset, int nois
     c.cD = (R)(2 * mu * mu * (1 + mu * mu) * tran);
     return c;
   };
+  p.margin_d[CC_WHEEL_FLOOR] = 0.0; p.margin_d[CC_TORSO_FLOOR] = 0.0; p.margin_d[CC_BLOCK_FLOOR] = 0.002; p.margin_d[CC_BLOCK_ROBOT] = 0.002;
   if (family == 1 && variant != ENV02_V1) p.cc[CC_WHEEL_FLOOR] = mk(0.9, 0.02, 0.5, 0.5, 0.5, 0.002, 0.0, tran_wheel);  // explicit <pair>s
   else p.cc[CC_WHEEL_FLOOR] = mk(1.0, 0.02, 1.0, 0.9, 0.95, 0.001, 0.0, tran_wheel);
   p.cc[CC_TORSO_FLOOR] = mk(1.0, 0.02, 1.0, 0.9, 0.95, 0.001, 0.0, tran_torso);

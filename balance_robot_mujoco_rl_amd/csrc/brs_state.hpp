@@ -18,7 +18,10 @@ template <bool BLK> struct Layout {
   static constexpr int NQ = BLK ? 16 : 9, NV = BLK ? 14 : 8;
   // fp64 fields
   static constexpr int D_P = 0, D_Q = 3, D_TH = 7, D_TIME = 9, D_XQ = 10, D_XP = 14, D_BP = 17, D_BQ = 20, D_TIMER = 24;
-  static constexpr int ND = BLK ? 25 : 17;
+  static constexpr int ND_POSE = BLK ? 25 : 17;
+  // fp64 velocity accumulators behind the fp32 qvel fields (BRS_VEL64): v 3, w 3, ww 2, (bv 3, bw 3)
+  static constexpr int D_V = ND_POSE, D_W = D_V + 3, D_WW = D_V + 6, D_BV = D_V + 8, D_BW = D_V + 11;
+  static constexpr int ND = ND_POSE + (BRS_VEL64 ? NV : 0);
   // fp32 fields
   static constexpr int F_V = 0, F_W = 3, F_WW = 6, F_A = 8, F_LASTPITCH = 8 + NV, F_EPRET = 9 + NV, F_BV = 10 + NV,
                        F_BW = 13 + NV;
@@ -54,6 +57,15 @@ BRS_HD void load_state_phys(EnvState<R, BLK>& S, const double* d, const FT* f, c
 #pragma unroll
     for (int k = 0; k < 4; k++) S.bq[k] = d[(L::D_BQ + k) * N + i];
   }
+#if BRS_VEL64
+#pragma unroll
+  for (int k = 0; k < 3; k++) { S.vd[k] = d[(L::D_V + k) * N + i]; S.wd[k] = d[(L::D_W + k) * N + i]; S.v[k] = (R)S.vd[k]; S.w[k] = (R)S.wd[k]; }
+  S.wwd[0] = d[(L::D_WW + 0) * N + i]; S.wwd[1] = d[(L::D_WW + 1) * N + i]; S.ww[0] = (R)S.wwd[0]; S.ww[1] = (R)S.wwd[1];
+  if constexpr (BLK) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) { S.bvd[k] = d[(L::D_BV + k) * N + i]; S.bwd[k] = d[(L::D_BW + k) * N + i]; S.bv[k] = (R)S.bvd[k]; S.bw[k] = (R)S.bwd[k]; }
+  }
+#endif
   S.rng_ctr = (uint32_t)ii[L::I_RNG * N + i];
   S.side_front = ii[L::I_SIDE * N + i];
   S.muw = (R)f[L::F_MUW * N + i];
@@ -104,6 +116,15 @@ BRS_HD void store_state(const EnvState<R, BLK>& S, double* d, FT* f, int* ii, si
     for (int k = 0; k < 4; k++) d[(L::D_BQ + k) * N + i] = S.bq[k];
     d[L::D_TIMER * N + i] = S.block_timer;
   }
+#if BRS_VEL64
+#pragma unroll
+  for (int k = 0; k < 3; k++) { d[(L::D_V + k) * N + i] = S.vd[k]; d[(L::D_W + k) * N + i] = S.wd[k]; }
+  d[(L::D_WW + 0) * N + i] = S.wwd[0]; d[(L::D_WW + 1) * N + i] = S.wwd[1];
+  if constexpr (BLK) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) { d[(L::D_BV + k) * N + i] = S.bvd[k]; d[(L::D_BW + k) * N + i] = S.bwd[k]; }
+  }
+#endif
   ii[L::I_ELAPSED * N + i] = S.elapsed;
   ii[L::I_RNG * N + i] = (int)S.rng_ctr;
   ii[L::I_SIDE * N + i] = S.side_front;
@@ -181,7 +202,8 @@ BRS_HD void env_step_idx(const Params<R>& P, Store<R>& st, Stream<R>& rng, doubl
   using L = Layout<BLK>;
   using SimT = Sim<R, BLK>;
   EnvState<R, BLK> S;
-  R ctrlL, ctrlR, rew;
+  CtrlT<R> ctrlL, ctrlR;
+  R rew;
   {
     const size_t i = idx.get();
     load_state_phys<R, BLK, FT>(S, d, f, ii, N, i);
@@ -249,7 +271,7 @@ BRS_HD void env_step_mem(const Params<R>& P, Store<R>& st, Stream<R>& rng, doubl
 
 // physics only (parity tests): nsub substeps with ctrl held, same flattened loop
 template <typename R, bool BLK, typename FT>
-BRS_HD void physics_mem(const Params<R>& P, Store<R>& st, double* d, FT* f, int* ii, size_t N, size_t i, R ctrlL, R ctrlR, int nsub) {
+BRS_HD void physics_mem(const Params<R>& P, Store<R>& st, double* d, FT* f, int* ii, size_t N, size_t i, CtrlT<R> ctrlL, CtrlT<R> ctrlR, int nsub) {
   using SimT = Sim<R, BLK>;
   EnvState<R, BLK> S;
   load_state<R, BLK, FT>(S, d, f, ii, N, i);
@@ -335,6 +357,9 @@ inline void set_state(double* d, FT* f, size_t N, const double* qpos, const doub
       f[(L::F_WW + 0) * N + i] = (FT)v[6]; f[(L::F_WW + 1) * N + i] = (FT)v[7];
       if (BLK)
         for (int k = 0; k < 3; k++) { f[(L::F_BV + k) * N + i] = (FT)v[8 + k]; f[(L::F_BW + k) * N + i] = (FT)v[11 + k]; }
+#if BRS_VEL64
+      for (int k = 0; k < L::NV; k++) d[(L::D_V + k) * N + i] = v[k];  // same order as qvel: v 3, w 3, ww 2, bv 3, bw 3
+#endif
     }
     if (warm) {  // world-frame linear accelerations -> body-frame linear coordinates of the solver variable
       const double* a = warm + i * L::NV;
@@ -374,6 +399,9 @@ inline void get_state(const double* d, const FT* f, size_t N, double* qpos, doub
       v[6] = f[(L::F_WW + 0) * N + i]; v[7] = f[(L::F_WW + 1) * N + i];
       if (BLK)
         for (int k = 0; k < 3; k++) { v[8 + k] = f[(L::F_BV + k) * N + i]; v[11 + k] = f[(L::F_BW + k) * N + i]; }
+#if BRS_VEL64
+      for (int k = 0; k < L::NV; k++) v[k] = d[(L::D_V + k) * N + i];
+#endif
     }
     if (warm) {
       double* a = warm + i * L::NV;

@@ -68,7 +68,7 @@ template <typename R, bool BLK> struct HostSim : IHost {
     for (size_t i = 0; i < N; i++) {
       R buf[LDS_WORDS_ENV03];
       Store<R> st{buf, 1};
-      physics_mem<R, BLK, R>(P, st, d.data(), f.data(), ii.data(), N, i, (R)ctrl[2 * i], (R)ctrl[2 * i + 1], nsub);
+      physics_mem<R, BLK, R>(P, st, d.data(), f.data(), ii.data(), N, i, (CtrlT<R>)ctrl[2 * i], (CtrlT<R>)ctrl[2 * i + 1], nsub);
     }
   }
   void reset(const uint8_t* mask, float* obs) override {
@@ -107,7 +107,7 @@ template <typename R, bool BLK> struct HostSim : IHost {
     load_state<R, BLK>(S, d.data(), f.data(), ii.data(), N, i);
     Stream<R> rng;
     open_stream(rng, S, i);
-    R cl, cr;
+    CtrlT<R> cl, cr;
     R r = Sim<R, BLK>::env_pre(P, S, rng, act[0], act[1], cl, cr);
     ctrl[0] = (double)cl; ctrl[1] = (double)cr;
     close_stream(rng, S, i);
