@@ -36,12 +36,19 @@ def hipcc_path():
     return "hipcc"
 
 
-def build(force=False, verbose=False):
-    """compile the HIP kernels + C ABI for gfx950 in-tree (hipcc cross-compiles without a GPU)"""
+def build(force=False, verbose=False, out=None, extra_flags=()):
+    """compile the HIP kernels + C ABI for gfx950 in-tree (hipcc cross-compiles without a GPU).  `out` / `extra_flags`: an A/B
+    build next to the product library (tools/ab_build.py; loaded only when BRS_HIP_LIB points at it)"""
     srcs = [SRC, SRC_POLICY] + HEADERS
+    if out is not None:
+        return _compile(out, verbose, list(extra_flags), tag="_" + os.path.splitext(os.path.basename(out))[0])
     stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if not (force or stale):
         return LIB_PATH
+    return _compile(LIB_PATH, verbose, [], tag="")
+
+
+def _compile(lib_path, verbose, extra_flags, tag):
     hipcc = hipcc_path()
     base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
     # step kernels: -ffast-math on the DEVICE side only (the host-side state conversion keeps IEEE semantics): no IEEE
@@ -56,14 +63,15 @@ def build(force=False, verbose=False):
                  # an independent one for a lone wave).  The ILP strategy: +4.3 % Env03, +2.7 % Env01 (same-box A/B)
                  "-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
     sim_flags += os.environ.get("BRS_EXTRA_HIPCC_FLAGS", "").split()  # ablation builds (e.g. -DBRS_NO_COUPLED); not for production
+    sim_flags += extra_flags
     if verbose:
         sim_flags.append("-Rpass-analysis=kernel-resource-usage")
-    obj_sim, obj_pol = os.path.join(_PKG, "csrc", "brs_kernels.o"), os.path.join(_PKG, "csrc", "brs_policy.o")
+    obj_sim, obj_pol = os.path.join(_PKG, "csrc", f"brs_kernels{tag}.o"), os.path.join(_PKG, "csrc", f"brs_policy{tag}.o")
     subprocess.check_call(base + sim_flags + ["-c", "-o", obj_sim, SRC])
     # policy / GAE kernels: IEEE math (tanh, exp, log at libm accuracy): the parity test is rtol 1e-5 against fp32 torch
     subprocess.check_call(base + ["-c", "-o", obj_pol, SRC_POLICY])
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, obj_sim, obj_pol])
-    return LIB_PATH
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path, obj_sim, obj_pol])
+    return lib_path
 
 
 _lib = None
@@ -74,10 +82,11 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+    path = os.environ.get("BRS_HIP_LIB") or LIB_PATH  # BRS_HIP_LIB: another BUILD of the same HIP library (same-box A/B runs)
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(hipcc --offload-arch=gfx950); there is no CPU fallback")
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     vp, dp, fp, u8p = C.c_void_p, C.POINTER(C.c_double), C.c_void_p, C.c_void_p
     L.brs_create.argtypes = [C.POINTER(BrsConfig), C.POINTER(vp)]
     L.brs_destroy.argtypes = [vp]
