@@ -1,5 +1,6 @@
 """ctypes binding of libbrs_hip.so (C ABI: include/brs.h).  Loading never needs a GPU; brs_create does."""
 import ctypes as C
+import hashlib
 import os
 import subprocess
 
@@ -13,7 +14,7 @@ HEADERS = [os.path.join(_PKG, "csrc", h) for h in ("brs_core.hpp", "brs_model.hp
 # every symbol include/brs.h declares
 SYMBOLS = ["brs_create", "brs_destroy", "brs_last_error", "brs_sizes", "brs_reset", "brs_step", "brs_physics",
            "brs_get_state", "brs_set_state", "brs_get_aux", "brs_set_aux", "brs_get_xpose", "brs_set_xpose",
-           "brs_step_bytes_per_env", "brs_step_kernel_name",
+           "brs_step_bytes_per_env", "brs_step_kernel_name", "brs_build_id",
            # include/brs_policy.h
            "brs_policy_create", "brs_policy_destroy", "brs_policy_last_error", "brs_policy_set_weights",
            "brs_policy_use_device_weights", "brs_policy_act", "brs_policy_value", "brs_rollout_bootstrap", "brs_gae"]
@@ -67,6 +68,12 @@ def _compile(lib_path, verbose, extra_flags, tag):
     if verbose:
         sim_flags.append("-Rpass-analysis=kernel-resource-usage")
     obj_sim, obj_pol = os.path.join(_PKG, "csrc", f"brs_kernels{tag}.o"), os.path.join(_PKG, "csrc", f"brs_policy{tag}.o")
+    # build id = hash of every source the library is made from + the flags: ties a committed rocprof summary to the code that ran
+    hsh = hashlib.sha256()
+    for f in sorted([SRC, SRC_POLICY] + HEADERS):
+        hsh.update(open(f, "rb").read())
+    hsh.update(" ".join(base[1:] + [a for a in sim_flags if not a.startswith("-Rpass")]).encode())
+    sim_flags = sim_flags + [f'-DBRS_BUILD_ID="{hsh.hexdigest()[:16]}"']
     subprocess.check_call(base + sim_flags + ["-c", "-o", obj_sim, SRC])
     # policy / GAE kernels: IEEE math (tanh, exp, log at libm accuracy): the parity test is rtol 1e-5 against fp32 torch
     subprocess.check_call(base + ["-c", "-o", obj_pol, SRC_POLICY])
@@ -106,6 +113,8 @@ def lib():
     L.brs_step_bytes_per_env.restype = C.c_int64
     L.brs_step_kernel_name.argtypes = [vp]
     L.brs_step_kernel_name.restype = C.c_char_p
+    L.brs_build_id.argtypes = []
+    L.brs_build_id.restype = C.c_char_p
     i32, u64, i64, u32, f32 = C.c_int32, C.c_uint64, C.c_int64, C.c_uint32, C.c_float
     L.brs_policy_create.argtypes = [i32, C.POINTER(vp)]
     L.brs_policy_destroy.argtypes = [vp]
@@ -119,3 +128,8 @@ def lib():
     L.brs_gae.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp]
     _lib = L
     return L
+
+
+def build_id():
+    """id of the loaded library's build (include/brs.h: brs_build_id)"""
+    return lib().brs_build_id().decode()

@@ -453,11 +453,16 @@ int brs_step(brs_handle* h, const float* actions_dev, float* obs_dev, float* rew
   }
 #undef BRS_LAUNCH_STEP
 #undef BRS_LAUNCH_OCC2
-  if (h->blk) {  // lanes of the NEXT step; without grouping the counts the step kernel left are just cleared
-    if (h->grouping) hipLaunchKernelGGL(brs_group_kernel, dim3((h->N + GROUP_ENVS - 1) / GROUP_ENVS), dim3(GROUP_THREADS), 0, s, h->N, h->keys(), h->perm(), h->counters());
-    else (void)hipMemsetAsync(h->counters(), 0, GROUP_WORDS * sizeof(int), s);
-  }
+  // a step launch that failed left no bucket counts: the grouping kernel must not run on them (its output would not be a
+  // permutation, and later steps would skip or double envs)
   BRS_HIP_TRY(h, hipGetLastError());
+  if (h->blk) {  // lanes of the NEXT step; without grouping the counts the step kernel left are just cleared
+    if (h->grouping) {
+      hipLaunchKernelGGL(brs_group_kernel, dim3((h->N + GROUP_ENVS - 1) / GROUP_ENVS), dim3(GROUP_THREADS), 0, s, h->N, h->keys(), h->perm(), h->counters());
+      BRS_HIP_TRY(h, hipGetLastError());
+    } else
+      BRS_HIP_TRY(h, hipMemsetAsync(h->counters(), 0, GROUP_WORDS * sizeof(int), s));
+  }
   return BRS_OK;
 }
 
@@ -529,6 +534,10 @@ int brs_debug_counters(unsigned long long* out16) {
   return BRS_OK;
 }
 #endif
+#ifndef BRS_BUILD_ID
+#define BRS_BUILD_ID "unstamped"
+#endif
+const char* brs_build_id(void) { return BRS_BUILD_ID; }
 const char* brs_step_kernel_name(const brs_handle* h) {
   if (!h) return "";
   // the instantiation brs_step launches, spelled as rocprofv3 prints it

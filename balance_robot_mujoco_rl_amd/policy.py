@@ -41,6 +41,16 @@ def _p(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+def _need(t, name, dtype, shape, device):
+    """the C ABI takes raw pointers: a sliced, float64 or host tensor would be read as garbage without any error"""
+    if not isinstance(t, torch.Tensor) or not t.is_cuda or t.device != device:
+        raise ValueError(f"{name}: expected a tensor on {device}, got {getattr(t, 'device', type(t))}")
+    if t.dtype != dtype or not t.is_contiguous() or tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name}: expected contiguous {dtype} of shape {tuple(shape)}, got {t.dtype} {tuple(t.shape)} "
+                         f"(contiguous: {t.is_contiguous()})")
+    return t
+
+
 class DevicePolicy:
     """SB3's MlpPolicy (6-64-64 tanh actor and critic, state-independent log-std) evaluated by the HIP kernels"""
 
@@ -95,11 +105,15 @@ class DevicePolicy:
         """obs [n,6] f32 cuda -> (action [n,2] unclipped, action_clipped [n,2], logp [n], value [n]); `out` = the same four
         preallocated tensors (e.g. rows of a DeviceRollout)"""
         n = obs.shape[0]
+        d, f32 = self.device, torch.float32
+        _need(obs, "obs", f32, (n, 6), d)
         if out is None:
-            d = self.device
-            out = (torch.empty((n, 2), dtype=torch.float32, device=d), torch.empty((n, 2), dtype=torch.float32, device=d),
-                   torch.empty(n, dtype=torch.float32, device=d), torch.empty(n, dtype=torch.float32, device=d))
+            out = (torch.empty((n, 2), dtype=f32, device=d), torch.empty((n, 2), dtype=f32, device=d),
+                   torch.empty(n, dtype=f32, device=d), torch.empty(n, dtype=f32, device=d))
         a, ac, lp, v = out
+        _need(a, "action", f32, (n, 2), d); _need(ac, "action_clipped", f32, (n, 2), d); _need(lp, "logp", f32, (n,), d); _need(v, "value", f32, (n,), d)
+        if noise is not None:
+            _need(noise, "noise", f32, (n, 2), d)
         self._check(self.L.brs_policy_act(self.h, n, _p(obs), self.seed, self.env_index_base, int(step) & 0xffffffff,
                                           int(bool(deterministic)), _p(a), _p(ac), _p(lp), _p(v), _p(noise), self._stream()),
                     "brs_policy_act")
@@ -107,13 +121,18 @@ class DevicePolicy:
 
     def value(self, obs, out=None):
         n = obs.shape[0]
+        _need(obs, "obs", torch.float32, (n, 6), self.device)
         if out is None:
             out = torch.empty(n, dtype=torch.float32, device=self.device)
+        _need(out, "value", torch.float32, (n,), self.device)
         self._check(self.L.brs_policy_value(self.h, n, _p(obs), _p(out), self._stream()), "brs_policy_value")
         return out
 
     def bootstrap(self, terminal_obs, terminated, truncated, gamma, reward):
         """reward += gamma * V(terminal_obs) where truncated and not terminated (in place)"""
+        n, d = reward.shape[0], self.device
+        _need(reward, "reward", torch.float32, (n,), d); _need(terminal_obs, "terminal_obs", torch.float32, (n, 6), d)
+        _need(terminated, "terminated", torch.uint8, (n,), d); _need(truncated, "truncated", torch.uint8, (n,), d)
         self._check(self.L.brs_rollout_bootstrap(self.h, reward.shape[0], _p(terminal_obs), _p(terminated), _p(truncated),
                                                  float(gamma), _p(reward), self._stream()), "brs_rollout_bootstrap")
         return reward

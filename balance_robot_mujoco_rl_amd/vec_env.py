@@ -60,6 +60,21 @@ class LazyInfos(list):
         self._materialise()
         return (list, (list(list.__iter__(self)),))
 
+    # every other way into the list goes through the C slots of `list`, which would see (or overwrite) the placeholder of a
+    # finished env: materialise first.  Unfinished envs still SHARE one empty dict -- a wrapper that wants to write into
+    # infos[i] of an unfinished env must assign a fresh dict (infos[i] = {...}), as SB3's own wrappers do.
+    def _m(name):
+        def f(self, *a, **k):
+            self._materialise()
+            return getattr(list, name)(self, *a, **k)
+        f.__name__ = name
+        return f
+
+    for _n in ("__setitem__", "__delitem__", "__contains__", "__reversed__", "__add__", "__mul__", "__rmul__", "__len__", "__ne__",
+               "copy", "index", "count", "sort", "reverse", "pop", "insert", "append", "extend", "remove", "__iadd__", "__imul__"):
+        locals()[_n] = _m(_n)
+    del _m, _n
+
 try:  # SB3 is optional: the class is a real VecEnv subclass when it is importable
     from stable_baselines3.common.vec_env import VecEnv as _VecEnvBase  # type: ignore
     _HAVE_SB3 = True

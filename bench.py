@@ -23,6 +23,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X spec (MI355X_MICROARCH.md chip table; 6.29 TB/s measured copy)
 FP32_VALU_PEAK_TFLOPS = 157.3
+# committed rocprofv3 summaries of the default command per env id (tools/profile_round.sh); each carries the build id it measured
+PROFILE_SUMMARY = {"Env03-v2": "r03_env03_summary.json", "Env01-v2": "r03_env01_summary.json"}
 
 
 def cpu_baseline(env_id, seconds_budget=12.0):
@@ -295,28 +297,40 @@ def main():
             "substeps_per_s": value * 250,
             "last_step_terminated": n_done,
         }
-        # HBM bytes per launch from the PMC counters cannot be collected from inside this process; when the committed
-        # rocprofv3 summary of this exact workload exists, report its per-launch figure (separate --pmc passes,
-        # FETCH_SIZE / WRITE_SIZE as MI355X_MICROARCH.md prescribes), else null
-        try:
-            if args.env == "Env03-v2" and n == 65536 and S == 1:
-                summ = json.load(open(os.path.join(ROOT, "profiles", "r02_env03_summary.json")))
-                out["roofline"]["traffic"] = summ["hbm_traffic"]["bytes_per_launch"]
-                out["roofline"]["valu"] = summ.get("valu")
-                if out["roofline"]["valu"]:
-                    # the resource that does bind: VALU issue.  Instructions per wave-step from the committed PMC run, time from
-                    # THIS run; peak = one VALU instruction per 4 clocks per SIMD at the 2.4 GHz boost clock, 1,024 SIMDs
-                    v = dict(out["roofline"]["valu"])
-                    waves = (n + 63) // 64
-                    rate = v["valu_insts_per_wave_per_step"] * waves / (kern_ms * 1e-3)
-                    v["valu_wave_insts_per_s"] = rate
-                    v["peak_valu_wave_insts_per_s"] = 1024 * 2.4e9 / 4
-                    v["issue_frac_of_peak_at_2.4GHz"] = rate / v["peak_valu_wave_insts_per_s"]
-                    out["roofline"]["valu"] = v
-                out["roofline"]["traffic_source"] = "profiles/r02_env03_summary.json (rocprofv3 --pmc, same command line)"
-        except Exception:
-            pass
-        if not args.no_cpu_baseline and world == 1:
+        # HBM bytes per launch and the VALU instruction counts come from PMC counters, which cannot be collected from inside
+        # this process: they are DERIVED FROM THE COMMITTED PROFILE of this exact command (separate rocprofv3 --pmc passes,
+        # FETCH_SIZE / WRITE_SIZE as MI355X_MICROARCH.md prescribes) -- and only when that profile carries the build id of
+        # the library that ran just now (include/brs.h: brs_build_id = hash of the kernel sources and flags); else null
+        out["build_id"] = _lib.build_id()
+        prof_path = os.path.join(ROOT, "profiles", PROFILE_SUMMARY.get(args.env, ""))
+        out["roofline"]["derived_from_profile"] = None
+        if n == 65536 and S == 1 and os.path.isfile(prof_path):
+            try:
+                summ = json.load(open(prof_path))
+                if summ.get("build_id") != out["build_id"]:
+                    out["roofline"]["stale_profile"] = (f"{os.path.relpath(prof_path, ROOT)} was measured on build {summ.get('build_id')}, this "
+                                                        f"library is {out['build_id']}: traffic / valu withheld (re-run tools/profile_round.sh)")
+                else:
+                    out["roofline"]["traffic"] = summ["hbm_traffic"]["bytes_per_launch"]
+                    out["roofline"]["derived_from_profile"] = os.path.relpath(prof_path, ROOT)
+                    pv = summ.get("valu")
+                    if pv:
+                        # the resource that binds: VALU issue.  Instructions per wave-step from the profile's PMC run, time from THIS
+                        # run.  Two ceilings at the 2.4 GHz boost clock over 1,024 SIMDs: the CHIP's (one wave64 VALU instruction
+                        # per 2 clocks per SIMD, reachable only with >= 2 resident waves: MI355X_MICROARCH.md, wave scheduling)
+                        # and what ONE resident wave per SIMD can issue (one per 4 clocks) -- 65,536 envs are 1,024 waves
+                        v = dict(pv)
+                        waves = (n + 63) // 64
+                        rate = v["valu_insts_per_wave_per_step"] * waves / (kern_ms * 1e-3)
+                        v["valu_wave_insts_per_s"] = rate
+                        v["chip_peak_valu_wave_insts_per_s"] = 1024 * 2.4e9 / 2
+                        v["issue_frac_of_chip_peak"] = rate / v["chip_peak_valu_wave_insts_per_s"]
+                        v["issue_frac_of_one_wave_per_simd_ceiling"] = rate / (1024 * 2.4e9 / 4)
+                        out["roofline"]["valu"] = v
+                        out["roofline"]["binding_resource"] = "valu_issue"
+            except Exception as e:
+                out["roofline"]["stale_profile"] = f"profile summary unreadable: {e}"
+        if not args.no_cpu_baseline:  # rank 0's host cores, whatever the world size
             out["cpu_baseline"] = cpu_baseline(args.env)
             try:
                 out["cpu_baseline_closed_form"] = cpu_baseline_closed_form(args.env)

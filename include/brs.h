@@ -112,6 +112,9 @@ int brs_set_xpose(brs_handle* h, const double* xquat, const double* xpos);
 int64_t brs_step_bytes_per_env(const brs_handle* h);
 /* name of the step kernel (for matching rocprof rows) */
 const char* brs_step_kernel_name(const brs_handle* h);
+/* identity of this BUILD: hash of the kernel sources and compile flags it was made from (set by the build, "unstamped" if
+ * compiled by hand).  bench.py reports profile-derived counters only when they carry the id of the library that ran. */
+const char* brs_build_id(void);
 
 #ifdef __cplusplus
 }

@@ -12,24 +12,25 @@ pytestmark = pytest.mark.gpu
 
 TOL_QPOS = 1e-4
 
-# ---- parity gates (facts behind them: profiles/r02_parity_*.json, tools/parity_locate.py)
+# ---- parity gates (facts behind them: profiles/r03_parity_*.json, tools/parity_report.py)
 # An env-step is UPRIGHT if the torso axis is within 60 degrees of vertical when the step starts (the env terminates at
 # 50 degrees of pitch, so with auto-reset every step it keeps is upright).  FALLEN robots exist only with auto-reset off.
-#  G1  robot coordinates (torso position, quaternion, wheel angles), upright: max |dqpos| < 1e-4, ZERO exceptions.
-#  G2  block coordinates, upright: < 1e-4 except env-steps in which the block's first touch lands one 20 us substep
-#      apart in fp32 and fp64 (MuJoCo's contact damping -B v switches on at dist < margin: a force step of ~B v; the block's
-#      inertia is 1.7e-5 kg m^2, so its spin changes by ~0.1 rad/s): at most 5e-5 of the env-steps, never above 1e-3.
-#  G3  fallen robots (lying flat, wheels rubbing on the floor: stick-slip amplifies rounding in the wheel angles):
-#      at most 2e-4 of the env-steps above 1e-4, never above 1e-3 (measured with the floor-contact distances taken from the
-#      fp64 pose: 12 of ~180,000, max 2.2e-4; before that change 45, max 4.0e-4, and the gate stood at 2e-3 / 3e-3).
-G2_RATE, G2_CAP, G3_RATE, G3_CAP = 5e-5, 1e-3, 2e-4, 1e-3
+# Since round 3 (contact-existence and servo-clamp decisions from exact fp64 constants, fp64 velocity accumulators) the
+# north-star bound holds as a STRICT maximum in every group: 0 of 7.6 M campaign env-steps above 1e-4 (worst 8.6e-5, a block
+# quaternion under the balancing policy; robot coordinates 5.2e-5; fallen robots 7.2e-5).  The gates are that bound, with
+# zero exceptions, plus per-test caps at ~5-10x what the test's own sample measured (r03 GPU log), so that a regression of
+# one order of magnitude in the bulk fails even when no env-step crosses 1e-4:
+#  G1  robot coordinates (torso position, quaternion, wheel angles), upright: max |dqpos| < 1e-4
+#  G2  block coordinates, upright:                                            max |dqpos| < 1e-4
+#  G3  all coordinates of fallen robots (lying flat, wheels rubbing):         max |dqpos| < 1e-4
+# (round 2's gates allowed 5e-5 / 2e-4 of the env-steps above 1e-4 with caps at 1e-3, and one free outlier per test.)
 
 
 class Gates:
     def __init__(self):
         self.n = {"up": 0, "fallen": 0}
         self.robot_up_max = self.block_up_max = self.fallen_max = 0.0
-        self.block_up_over = self.fallen_over = 0
+        self.skipped = 0.0
 
     def add(self, qpos_pre, q_gpu, q_orc, skip=None):
         d = np.abs(q_gpu - q_orc)
@@ -40,20 +41,18 @@ class Gates:
         if up.any():
             self.robot_up_max = max(self.robot_up_max, float(d[up][:, :9].max()))
             if d.shape[1] > 9:
-                eb = d[up][:, 9:].max(axis=1)
-                self.block_up_max = max(self.block_up_max, float(eb.max())); self.block_up_over += int((eb > TOL_QPOS).sum())
+                self.block_up_max = max(self.block_up_max, float(d[up][:, 9:].max()))
         if (~up).any():
-            ef = d[~up].max(axis=1)
-            self.fallen_max = max(self.fallen_max, float(ef.max())); self.fallen_over += int((ef > TOL_QPOS).sum())
+            self.fallen_max = max(self.fallen_max, float(d[~up].max()))
 
-    def check(self, label):
-        print(f"{label}: upright {self.n['up']} env-steps: robot max {self.robot_up_max:.3g}, block max {self.block_up_max:.3g} "
-              f"({self.block_up_over} above 1e-4); fallen {self.n['fallen']}: max {self.fallen_max:.3g} ({self.fallen_over} above 1e-4)")
-        assert self.robot_up_max < TOL_QPOS, f"G1: robot coordinates {self.robot_up_max:.3g} on an upright env-step"
-        assert self.block_up_over <= max(1, int(G2_RATE * self.n["up"])) and self.block_up_max < G2_CAP, \
-            f"G2: {self.block_up_over} block outliers in {self.n['up']}, max {self.block_up_max:.3g}"
-        assert self.fallen_over <= max(1, int(G3_RATE * self.n["fallen"])) and self.fallen_max < G3_CAP, \
-            f"G3: {self.fallen_over} in {self.n['fallen']}, max {self.fallen_max:.3g}"
+    def check(self, label, robot_cap=TOL_QPOS, block_cap=TOL_QPOS, fallen_cap=TOL_QPOS):
+        """caps: what THIS test's sample may reach (<= the 1e-4 bound); printed values go to the GPU test log"""
+        print(f"{label}: upright {self.n['up']} env-steps: robot max {self.robot_up_max:.3g}, block max {self.block_up_max:.3g}; "
+              f"fallen {self.n['fallen']}: max {self.fallen_max:.3g}")
+        assert max(robot_cap, block_cap, fallen_cap) <= TOL_QPOS
+        assert self.robot_up_max < robot_cap, f"G1: robot coordinates {self.robot_up_max:.3g} on an upright env-step (cap {robot_cap:g})"
+        assert self.block_up_max < block_cap, f"G2: block coordinates {self.block_up_max:.3g} on an upright env-step (cap {block_cap:g})"
+        assert self.fallen_max < fallen_cap, f"G3: fallen robot {self.fallen_max:.3g} (cap {fallen_cap:g})"
 
 
 def _mk(env_id, n, **kw):
@@ -105,36 +104,55 @@ def test_teacher_forced_physics_parity(env_id, n, steps):
         g.add(qpos, qg, qo)
         assert np.array_equal(tg, to), "time accumulates identically (fp64, 250 additions of h)"
         assert np.isfinite(qg).all() and np.isfinite(vg).all()
-    g.check(env_id)
+    # measured (r03): robot 6.6e-9 / 3.4e-8 / 4.0e-9, block 5.1e-8, fallen 9.8e-6 / 6.3e-5 / 5.6e-8
+    g.check(env_id, robot_cap=1e-6, block_cap=1e-6)
     assert g.n["up"] > 0.15 * n * steps, "the rollout must cover upright env-steps"
     assert g.n["fallen"] > (0.05 if env_id == "Env02-v1" else 0.15) * n * steps, "... and robots that stay down"
 
 
-def _env_step_gates(env_id, n, steps, actions, seed=0):
-    """teacher-forced FULL env steps with auto-reset and shared Philox streams (the bench workload's dynamics)"""
+def _env_step_gates(env_id, n, steps, actions, seed=0, max_skip=0.2):
+    """teacher-forced FULL env steps with auto-reset and shared Philox streams (the bench workload's dynamics).
+    actions: "zero", "random" (U(-1,1)^2) or "policy" -- the reference's own MuJoCo-trained balance policy
+    (tests/quant_policy.py, envs/RobotMovePolicy.tflite) acting on the ORACLE's observations: robots that stay up for whole
+    episodes while blocks keep hitting them, the workload a trained policy produces"""
     torch, sim, orc = _mk(env_id, n, seed=seed, auto_reset=True, obs_noise=False)
-    sim.reset(); orc.reset()
+    sim.reset(); obs_o = orc.reset()
     rng = np.random.default_rng(1234)
+    pol = None
+    if actions == "policy":
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from quant_policy import QuantMovePolicy
+        qp = QuantMovePolicy()
+        pol = lambda o: qp.act(torch.from_numpy(np.ascontiguousarray(o, dtype=np.float32)), "mean").numpy()
     g = Gates()
+    nskip = 0
     for t in range(steps):
         qpos, qvel, warm, tm = orc.get_state()
         sim.set_state(qpos, qvel, warm, tm); sim.set_aux(orc.get_aux()); sim.set_xpose(*orc.get_xpose())
-        act = np.zeros((n, 2), np.float32) if actions == "zero" else rng.uniform(-1, 1, size=(n, 2)).astype(np.float32)
+        if pol is not None:
+            act = pol(obs_o)
+        else:
+            act = np.zeros((n, 2), np.float32) if actions == "zero" else rng.uniform(-1, 1, size=(n, 2)).astype(np.float32)
         og = [x.cpu().numpy().copy() for x in sim.step(torch.from_numpy(act).cuda())]
         oo = orc.step(act)
+        obs_o = oo[0]
         # a finished episode was re-drawn; a block removed / re-thrown on one side only is a discrete difference
         skip = og[2].astype(bool) | og[3].astype(bool) | oo[2] | oo[3]
         skip |= np.isnan(sim.get_aux()[:, 1]) != np.isnan(orc.get_aux()[:, 1])
-        assert n < 64 or skip.mean() < 0.2
+        nskip += int(skip.sum())
         g.add(qpos, sim.get_state()[0], orc.get_state()[0], skip)
     sim.close(); orc.close()
+    g.skipped = nskip / float(n * steps)
+    print(f"{env_id} {actions}: skipped {nskip} of {n * steps} env-steps ({100 * g.skipped:.2f} %: finished episodes, one-sided block removals)")
+    assert n < 64 or g.skipped < max_skip, f"skipped share {g.skipped:.3f}"
     return g
 
 
 def test_config1_env01_v2_single_env():
     """BASELINE config 1: Env01-v2, ONE env (a single lane of a single wave), 200 env steps against the oracle"""
     g = _env_step_gates("Env01-v2", 1, 200, "random", seed=2)
-    g.check("config 1 (Env01-v2, N = 1)")
+    g.check("config 1 (Env01-v2, N = 1)", robot_cap=1e-7)   # measured 1.1e-9
     assert g.n["up"] > 100
 
 
@@ -142,14 +160,67 @@ def test_config2_env01_v2_4096_zero_action():
     """BASELINE config 2: Env01-v2, 4,096 envs, zero action -- 100 teacher-forced env steps under pytest (the full 1,000
     steps: tools/parity_report.py -> profiles/r02_parity_report.json)"""
     g = _env_step_gates("Env01-v2", 4096, 100, "zero")
-    g.check("config 2 (Env01-v2, 4096 envs, zero action)")
-    assert g.robot_up_max < 2e-5, "zero-action rollouts sit far inside the tolerance"
+    g.check("config 2 (Env01-v2, 4096 envs, zero action)", robot_cap=2e-6)   # measured 2.2e-7 (round 2: 1.6e-6)
 
 
 def test_config3_env03_v2_random_policy_reduced():
     """BASELINE config 3 at a size the oracle finishes in a minute: Env03-v2, 2,048 envs x 60 steps, random policy"""
     g = _env_step_gates("Env03-v2", 2048, 60, "random")
-    g.check("config 3 reduced (Env03-v2, 2048 envs, random policy)")
+    g.check("config 3 reduced (Env03-v2, 2048 envs, random policy)", robot_cap=6e-5, block_cap=3e-5)   # measured 1.3e-5 / 1.4e-6
+
+
+def test_config3_under_the_reference_balancing_policy():
+    """the workload of profiles/r02_parity_config3_policy.json (round 2: 4 robot-coordinate env-steps per million above 1e-4):
+    Env03-v2, 1,024 envs x 150 steps with actions from the reference's MuJoCo-trained policy -- robots stay up while blocks
+    keep hitting them.  G1 with zero exceptions."""
+    g = _env_step_gates("Env03-v2", 1024, 150, "policy", max_skip=0.02)
+    g.check("config 3 under the balancing policy (Env03-v2, 1024 envs)", robot_cap=2e-5, block_cap=3e-5)   # measured 1.9e-6 / 3.3e-6
+    assert g.n["up"] > 0.95 * 1024 * 150, "under the policy the robots stay upright"
+
+
+def _constructed(env_id, qpos, qvel, ctrl, nsub):
+    """constructed states on the HIP path: set_state -> brs_physics(nsub) against the oracle; relative velocity error per env"""
+    from tests import constructed_states as cs
+    n = len(qpos)
+    torch, sim, orc = _mk(env_id, n, seed=0, auto_reset=False, obs_noise=False)
+    orc.set_state(qpos, qvel); sim.set_state(qpos, qvel)
+    orc.physics(ctrl, nsub); sim.physics(ctrl.astype(np.float32), nsub)
+    (qo, vo, _, _), (qg, vg, _, _) = orc.get_state(), sim.get_state()
+    sim.close(); orc.close()
+    assert np.isfinite(vg).all()
+    return cs.rel_vel_error(vo, vg), vo
+
+
+def test_constructed_block_robot_contact_states_on_the_hip_path():
+    """SURVEY f2 on the device build (sqrt64_ with its v_rsq_f32 seed, device rcp/rsqrt, fast-math contraction of the fp64
+    decision code): block against every torso face and both wheels, 5- and 6-point patches plus the wheel point -- the
+    states of tests/test_hostsim_parity.py::test_constructed_block_robot_contact_states, 5 substeps via brs_physics"""
+    from tests import constructed_states as cs
+    qpos, qvel = cs.block_robot_states()
+    err, vo = _constructed("Env03-v2", qpos, qvel, np.zeros((len(qpos), 2)), 5)
+    assert (np.abs(vo[:, :6]).max(axis=1) > 1e-6).sum() > len(qpos) // 3, "a coupled contact acted on the robot"
+    print(f"block<->robot constructed states on HIP: rel. velocity error q98 {np.quantile(err, 0.98):.3g}, max {err.max():.3g}")
+    assert np.quantile(err, 0.98) < 3e-6 and err.max() < 1e-5, (np.quantile(err, 0.98), err.max())   # measured 3.1e-7 / 7.0e-7
+
+
+def test_constructed_edge_edge_states_on_the_hip_path():
+    """one-point edge-edge patches between 0.5 mm outside and 1.5 mm inside the margin: existence decided from the fp64 poses"""
+    from tests import constructed_states as cs
+    qpos, qvel = cs.edge_edge_states()
+    err, vo = _constructed("Env03-v2", qpos, qvel, np.zeros((len(qpos), 2)), 5)
+    print(f"edge-edge constructed states on HIP: rel. velocity error q95 {np.quantile(err, 0.95):.3g}, max {err.max():.3g}")
+    assert np.quantile(err, 0.95) < 2e-6 and err.max() < 5e-6, (np.quantile(err, 0.95), err.max())   # measured 1.1e-7 / 1.5e-7: a point
+    # existing on one side only would show as ~1e-2
+
+
+def test_constructed_floor_contact_states_on_the_hip_path():
+    """robot pressed into the floor in every orientation (wheel rim / side / triangle points, torso corners, up to 8 slots)"""
+    from tests import constructed_states as cs
+    qpos, qvel = cs.floor_states()
+    ctrl = np.random.default_rng(5).uniform(-30, 30, size=(len(qpos), 2)).astype(np.float32).astype(np.float64)
+    err, vo = _constructed("Env01-v2", qpos, qvel, ctrl, 5)
+    print(f"floor constructed states on HIP: rel. velocity error q98 {np.quantile(err, 0.98):.3g}, max {err.max():.3g}")
+    assert np.quantile(err, 0.98) < 5e-7 and err.max() < 1e-6, (np.quantile(err, 0.98), err.max())   # measured 2.8e-8 / 3.8e-8
 
 
 def test_config4_per_node_total_on_one_gpu():
@@ -311,8 +382,7 @@ def test_ragged_batch_sizes(env_id, n):
         np.testing.assert_allclose(out_g[1], out_o[1], atol=1e-4, rtol=1e-5)
         done = out_g[2].astype(bool) | out_g[3].astype(bool) | out_o[2] | out_o[3]
         qg, qo = sim.get_state()[0], orc.get_state()[0]
-        assert np.abs(qg - qo)[~done][:, :9].max(initial=0.0) < TOL_QPOS          # G1
-        assert np.abs(qg - qo)[~done].max(initial=0.0) < G2_CAP                   # G2 (cap)
+        assert np.abs(qg - qo)[~done].max(initial=0.0) < TOL_QPOS                 # G1, G2
     sim.close(); orc.close()
 
 

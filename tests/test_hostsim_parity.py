@@ -8,6 +8,7 @@ import pytest
 
 from oracle import oracle as O
 from tests.hostsim.hostsim import HostSim
+from tests import constructed_states as cs
 
 
 def _rollout_parity(env_id, n, steps, double, seed=11):
@@ -66,26 +67,9 @@ def test_free_run_env_steps_match_with_shared_rng():
 def test_constructed_block_robot_contact_states(double, tol):
     """block placed (random pose, random approach velocity) against the torso faces and the wheels of an airborne robot:
     the kernel source and the oracle must generate the same contacts and the same impulses over 5 substeps -- the coupled
-    path on far more configurations than a rollout visits"""
-    rng = np.random.default_rng(17)
-    n = 96
-    TC, TS, BS = np.array([0.0, 0.0, 0.0995]), np.array([0.05, 0.0185, 0.0855]), 0.02
-    WP = {1: np.array([-0.074, 0.0, 0.034]), 2: np.array([0.074, 0.0, 0.034])}
-    qpos = np.zeros((n, 16)); qvel = np.zeros((n, 14))
-    qpos[:, 3] = 1.0; qpos[:, 2] = 1.0                      # robot 1 m up: no floor contacts
-    for i in range(n):
-        if i % 3 == 0:
-            face = rng.integers(3); sign = rng.choice([-1.0, 1.0])
-            c = TC + rng.uniform(-1, 1, 3) * TS
-            c[face] = TC[face] + sign * (TS[face] + BS * rng.uniform(0.7, 1.3))
-        else:
-            th = rng.uniform(0, 2 * np.pi); rad = 0.034 + BS * rng.uniform(0.7, 1.3)
-            c = WP[1 + i % 2] + np.array([rng.uniform(-1, 1) * 0.013, rad * np.cos(th), rad * np.sin(th)])
-        q = rng.normal(size=4); q /= np.linalg.norm(q)
-        qpos[i, 9:12] = c + np.array([0, 0, 1.0]); qpos[i, 12:16] = q
-        qvel[i, 8:11] = rng.normal(size=3) * 2.0             # block linear velocity (m/s), spin
-        qvel[i, 11:14] = rng.normal(size=3) * 5.0
-        qvel[i, 6:8] = rng.normal(size=2) * 10.0             # wheels spinning
+    path on far more configurations than a rollout visits (the same states on the HIP path: tests/test_gpu_parity.py)"""
+    qpos, qvel = cs.block_robot_states()
+    n = len(qpos)
     o = O.Oracle("Env03-v2", n, noise=False, threads=8)
     h = HostSim("Env03-v2", n, noise=False, double=double)
     o.set_state(qpos, qvel); h.set_state(qpos, qvel)
@@ -93,59 +77,50 @@ def test_constructed_block_robot_contact_states(double, tol):
     ctrl = np.zeros((n, 2))
     most = 0
     for _ in range(5):
-        most = max(most, max(sum(1 for c in o.forward(env=i)["contacts"] if c["body2"] == 4 and c["body1"] != 0) for i in range(n)))
+        most = max(most, int(cs.coupled_contact_count(o, n).max()))
         o.physics(ctrl, 1); h.physics(ctrl, 1)
     assert 5 <= most <= 7, most   # the states must exercise more than the 4 slots of round 1
-    (qo, vo, _, _), (qh, vh, _, _) = o.get_state(), h.get_state()
+    vo, vh = o.get_state()[1], h.get_state()[1]
     touched = np.abs(vo[:, :6]).max(axis=1) > 1e-6          # the robot was pushed: a coupled contact acted
     assert touched.sum() > n // 3
-    scale = 1.0 + np.abs(vo).max(axis=1)
-    err = np.abs(vo - vh).max(axis=1) / scale
+    err = cs.rel_vel_error(vo, vh)
     assert np.quantile(err, 0.98) < tol and err.max() < 50 * tol, (np.quantile(err, 0.98), err.max())
+
+
+@pytest.mark.parametrize("double,tol", [(True, 1e-12), (False, 1e-5)])
+def test_constructed_edge_edge_states(double, tol):
+    """block pushed edge-first against a vertical torso edge, between 0.5 mm outside and 1.5 mm inside the margin: the patch is
+    ONE point and whether it exists is the edge-axis separation against the margin (decided from the fp64 poses in the float
+    build as well)"""
+    qpos, qvel = cs.edge_edge_states()
+    n = len(qpos)
+    o = O.Oracle("Env03-v2", n, noise=False, threads=8)
+    h = HostSim("Env03-v2", n, noise=False, double=double)
+    o.set_state(qpos, qvel); h.set_state(qpos, qvel)
+    codes = [O.box_box_points(cs.TS, cs.BS, qpos[i, 9:12] - np.array([0, 0, 1.0]) - cs.TC, cs.quat_to_mat(qpos[i, 12:16]), 0.002)[3] for i in range(n)]
+    assert sum(c >= 6 for c in codes) > n // 2 and sum(c < 0 for c in codes) > 4, "edge-pair contacts and near misses"
+    ctrl = np.zeros((n, 2))
+    o.physics(ctrl, 5); h.physics(ctrl, 5)
+    vo, vh = o.get_state()[1], h.get_state()[1]
+    err = cs.rel_vel_error(vo, vh)
+    assert err.max() < 50 * tol and np.quantile(err, 0.95) < tol, (np.quantile(err, 0.95), err.max())
 
 
 @pytest.mark.parametrize("double,tol", [(True, 1e-12), (False, 5e-6)])
 def test_constructed_floor_contact_states(double, tol):
     """robot in random orientations (upright, on a wheel's side, on the torso, upside down) pressed 0..3 mm into the floor
     with random velocities: wheel rim / side / triangle points and torso corners, up to the 8-slot capacity"""
-    rng = np.random.default_rng(23)
-    n = 128
-    TC, TS = np.array([0.0, 0.0, 0.0995]), np.array([0.05, 0.0185, 0.0855])
-    WP = [np.array([-0.074, 0.0, 0.034]), np.array([0.074, 0.0, 0.034])]
-    pts = [TC + np.array([sx, sy, sz]) * TS for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)]
-    for w in WP:
-        for th in np.linspace(0, 2 * np.pi, 48, endpoint=False):
-            for ax in (-0.013, 0.013):
-                pts.append(w + np.array([ax, 0.034 * np.cos(th), 0.034 * np.sin(th)]))
-    pts = np.array(pts)
-    qpos = np.zeros((n, 9)); qvel = np.zeros((n, 8))
-    for i in range(n):
-        q = rng.normal(size=4)
-        if i % 4 == 0:
-            q = np.array([1.0, 0, 0, 0]) + 0.05 * rng.normal(size=4)     # near upright
-        elif i % 4 == 1:                                                  # lying on the torso's broad face (+-90 deg about x)
-            a = rng.choice([-1.0, 1.0]) * (np.pi / 2 + 0.02 * rng.normal())
-            q = np.array([np.cos(a / 2), np.sin(a / 2), 0, 0]) + 0.004 * rng.normal(size=4)
-        elif i % 4 == 2:                                                  # on a wheel's flat side (+-90 deg about y)
-            a = rng.choice([-1.0, 1.0]) * (np.pi / 2 + 0.02 * rng.normal())
-            q = np.array([np.cos(a / 2), 0, np.sin(a / 2), 0]) + 0.004 * rng.normal(size=4)
-        q /= np.linalg.norm(q)
-        w_, x, y, z = q
-        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w_ * z), 2 * (x * z + w_ * y)],
-                      [2 * (x * y + w_ * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w_ * x)],
-                      [2 * (x * z - w_ * y), 2 * (y * z + w_ * x), 1 - 2 * (x * x + y * y)]])
-        low = (pts @ R.T)[:, 2].min()
-        qpos[i, 3:7] = q; qpos[i, 2] = -0.02 - low - rng.uniform(0.0, 0.003 if i % 4 in (0, 3) else 0.015)   # flat poses pressed deeper: more points
-        qvel[i, :3] = rng.normal(size=3) * 0.3; qvel[i, 3:6] = rng.normal(size=3) * 2.0; qvel[i, 6:8] = rng.normal(size=2) * 15.0
+    qpos, qvel = cs.floor_states()
+    n = len(qpos)
     o = O.Oracle("Env01-v2", n, noise=False, threads=8)
     h = HostSim("Env01-v2", n, noise=False, double=double)
     o.set_state(qpos, qvel); h.set_state(qpos, qvel)
     ncon = np.array([o.forward(env=i)["ncon"] for i in range(n)])
     assert ncon.min() >= 1 and ncon.max() >= 6, (ncon.min(), ncon.max())
-    ctrl = rng.uniform(-30, 30, size=(n, 2))
+    ctrl = np.random.default_rng(5).uniform(-30, 30, size=(n, 2))
     o.physics(ctrl, 5); h.physics(ctrl, 5)
     vo, vh = o.get_state()[1], h.get_state()[1]
-    err = np.abs(vo - vh).max(axis=1) / (1.0 + np.abs(vo).max(axis=1))
+    err = cs.rel_vel_error(vo, vh)
     assert np.quantile(err, 0.98) < tol and err.max() < 50 * tol, (np.quantile(err, 0.98), err.max())
 
 

@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--actions", choices=["random", "zero", "policy"], default="random",
                     help="policy = the reference's MuJoCo-trained balance policy (tests/quant_policy.py) acting on the teacher's observations")
     ap.add_argument("--max-dump", type=int, default=40)
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_parity_outliers.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r03_parity_outliers.json"))
     a = ap.parse_args()
     n, thr = a.envs, min(os.cpu_count() or 1, 64)
     ar = bool(a.auto_reset)

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""Classify every dumped outlier of profiles/r02_parity_config*.json (tools/parity_locate.py output) into the causes named
-in DESIGN.md 2.1 and write profiles/r02_parity_report.json; exits non-zero if an outlier fits none of them."""
+"""Classify every dumped outlier of profiles/r03_parity_config*.json (tools/parity_locate.py output) into the causes named
+in DESIGN.md 2.1 and write profiles/r03_parity_report.json; exits non-zero if an outlier fits none of them."""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rep, unexplained = {}, 0
-for cfg in ("config2", "config3", "config3_noreset", "config3_large", "config3_policy"):
-    path = os.path.join(ROOT, "profiles", f"r02_parity_{cfg}.json")
+for cfg in ("config2", "config3", "config3_noreset", "config3_large", "config3_policy", "ids_Env01-v1", "ids_Env01-v3", "ids_Env02-v1", "ids_Env03-v1"):
+    path = os.path.join(ROOT, "profiles", f"r03_parity_{cfg}.json")
     if not os.path.exists(path):
         continue
     r = json.load(open(path))
@@ -51,6 +51,6 @@ rep["note"] = ("HIP fp32 kernel vs oracle/brs_oracle.c (fp64; own restatement, N
                "step of 250 substeps; per_group: robot = qpos[0:9], block = qpos[9:16]; upright = torso axis within 60 deg of vertical at the "
                "start of the step.  Causes: DESIGN.md section 2.1.")
 rep["unexplained_outliers"] = unexplained
-json.dump(rep, open(os.path.join(ROOT, "profiles", "r02_parity_report.json"), "w"), indent=1)
+json.dump(rep, open(os.path.join(ROOT, "profiles", "r03_parity_report.json"), "w"), indent=1)
 print(json.dumps({k: (v["outlier_classes"] if isinstance(v, dict) else v) for k, v in rep.items() if k != "note"}, indent=1))
 sys.exit(1 if unexplained else 0)

@@ -1,10 +1,10 @@
 #!/bin/bash
 # rocprofv3 evidence for the bench workload (run on the GPU box from the repo root):
 #   kernel-trace + stats of the default bench command, then SEPARATE --pmc passes (SQ issue counters, instruction cache,
-#   FETCH_SIZE, WRITE_SIZE) of a shorter run of the same command.  Everything lands under gpurun_out/prof_r02/; the
+#   FETCH_SIZE, WRITE_SIZE) of a shorter run of the same command.  Everything lands under gpurun_out/prof_round/; the
 #   summary tools/summarise_profile.py writes is what gets copied to profiles/.
 set -e
-OUT=${1:-gpurun_out/prof_r02}
+OUT=${1:-gpurun_out/prof_round}
 ENVARG=${2:-Env03-v2}
 mkdir -p $OUT
 export TMPDIR=/tmp

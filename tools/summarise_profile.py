@@ -1,18 +1,21 @@
 #!/usr/bin/env python3
-"""Condense a tools/profile_r02.sh output directory (rocprofv3's rocpd SQLite files) into one JSON -- what is committed
+"""Condense a tools/profile_round.sh output directory (rocprofv3's rocpd SQLite files) into one JSON -- what is committed
 under profiles/.  PMC values are reported per shader-engine instance by rocprofv3: a dispatch's figure is the SUM over
 its instances."""
 import glob, json, os, sqlite3, sys
 import numpy as np
 
 out, env = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "Env03-v2")
-kname = "brs_step_kernel<true>" if env.startswith("Env03") else "brs_step_kernel<false>"
+kname = "brs_step_kernel<true, *>" if env.startswith("Env03") else "brs_step_kernel_occ2<*>"
 res = {"command": f"python3 bench.py --env {env} --steps 300 --warmup 20 (rocprofv3 --kernel-trace --stats); PMC: the same command with --steps 40 "
                   "--warmup 10, one rocprofv3 --pmc run per counter set, mean over the LAST 30 dispatches of the step kernel "
                   "(bench.py pre-rolls >= 300 env steps, so all of them are steady state)",
        "kernel": kname}
 try:
     res["bench"] = json.loads(open(os.path.join(out, "bench.json")).read().strip().splitlines()[-1])
+    # the build these counters belong to (include/brs.h: brs_build_id): bench.py uses them only for a library with this id
+    res["build_id"] = res["bench"].get("build_id")
+    res["bench"]["roofline"].pop("valu", None); res["bench"]["roofline"].pop("traffic", None)   # (derived from an OLDER summary, if at all)
 except Exception as e:
     res["bench_error"] = str(e)
 tr = os.path.join(out, "trace", "trace_results.db")
