@@ -243,6 +243,9 @@ def main():
     ap.add_argument("--eval-envs", type=int, default=4096)
     ap.add_argument("--device-rollout", action="store_true",
                     help="act, bootstrap and GAE with the HIP kernels of include/brs_policy.h instead of torch ops")
+    ap.add_argument("--obs-init-scale", default="", help="comma-separated factors on the INITIAL first-layer weights per observation "
+                    "channel (both towers), e.g. 1,0.1,1,1,1,1: Env01-v2's obs[1] is a finite difference of two noisy pitch samples "
+                    "(+-10 rad/s of noise, envs/env01_v2.py:16-20 with RobotBaseEnv.py:142-157) and saturates freshly initialised tanh units")
     ap.add_argument("--save", default="", help="write the policy/value weights (torch state_dict) here")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
@@ -259,6 +262,10 @@ def main():
     torch.manual_seed(a.seed)   # identical initial weights on every rank
     dev = torch.device("cuda", local)
     model = ActorCritic(a.log_std_init).to(dev)
+    if a.obs_init_scale:
+        sc = torch.tensor([float(x) for x in a.obs_init_scale.split(",")], device=dev)
+        with torch.no_grad():
+            model.pi[0].weight.mul_(sc); model.v[0].weight.mul_(sc)
     torch.manual_seed(1000 * (a.seed + 1) + rank)   # ... different action noise
     base = rank * a.envs
     opt = torch.optim.Adam(model.parameters(), lr=a.lr)
