@@ -146,7 +146,13 @@ def train(sim, model, opt, iters, n_steps, epochs, minibatch, gamma, lam, clip, 
                     adv[t] = g
                 ret = adv + B["val"]
             if norm_returns:
-                model.ret_scale.lerp_(_allreduce_mean_(ret.std()).clamp(min=1.0), 0.05 if it else 1.0)   # same on all ranks
+                new_scale = _allreduce_mean_(ret.std()).clamp(min=1.0)   # same on all ranks
+                if it == 0 and float(model.ret_scale) == 1.0:
+                    # the unit is switched on here (e.g. at the start of the second phase): keep the critic's predictions where
+                    # they are by folding the change of unit into its last layer
+                    k = float(model.ret_scale / new_scale)
+                    model.v[4].weight.mul_(k); model.v[4].bias.mul_(k)
+                model.ret_scale.lerp_(new_scale, 0.05 if it else 1.0)
         flat = {k: v.reshape((-1,) + v.shape[2:]) for k, v in B.items()}
         fadv = adv.reshape(-1); fret = ret.reshape(-1)
         N = fadv.numel()
@@ -235,7 +241,9 @@ def main():
     ap.add_argument("--critic-warmup2", type=int, default=0, help="value-only iterations at the start of the second phase")
     ap.add_argument("--lr2-end", type=float, default=None, help="anneal the second phase's learning rate linearly to this")
     ap.add_argument("--norm-returns", action="store_true", help="critic in units of the running std of the returns")
+    ap.add_argument("--norm-returns2", action="store_true", help="... from the second phase on")
     ap.add_argument("--target-kl", type=float, default=None, help="stop an iteration's updates at 1.5x this approximate KL")
+    ap.add_argument("--target-kl2", type=float, default=None, help="... in the second phase only")
     ap.add_argument("--seed", type=int, default=0, help="seeds the initial weights, the action noise and the env streams")
     ap.add_argument("--mix2", type=float, default=0.0, help="share of the envs kept in --env during the second phase")
     ap.add_argument("--reward-clip", type=float, default=None, help="learner-side upper clip of the per-step reward")
@@ -292,7 +300,8 @@ def main():
         else:
             sim = BatchedSim(env_id, a.envs, device=local, seed=2 * a.seed, env_index_base=base, auto_reset=True)
         train(sim, model, opt, iters, a.n_steps, a.epochs, a.minibatch, a.gamma, a.lam, 0.2, log, env_id, a.ent, a.reward_clip,
-              warm, a.lr2_end if phase == 1 else None, a.norm_returns, a.target_kl, a.device_rollout, 1000 * (a.seed + 1) + phase, base)
+              warm, a.lr2_end if phase == 1 else None, a.norm_returns or (phase == 1 and a.norm_returns2),
+              a.target_kl2 if (phase == 1 and a.target_kl2 is not None) else a.target_kl, a.device_rollout, 1000 * (a.seed + 1) + phase, base)
         sim.close()
     evals = []
     if world > 1:
