@@ -70,6 +70,11 @@ __device__ __forceinline__ unsigned long long* brs_tim_slots() {  // 16 x u64 pe
 #ifndef BRS_VEL64
 #define BRS_VEL64 1
 #endif
+// the block<->torso patch in PATCH-FRAME algebra (Sim::Patch below): per point ~60 instructions in a 6-dof twist space shared by
+// all points of the patch, one 6x6 congruence per pass into H -- instead of a rank-3 update of the 12x12 dof block per point
+#ifndef BRS_PATCH_FRAME
+#define BRS_PATCH_FRAME 1
+#endif
 
 namespace brs {
 
@@ -714,6 +719,63 @@ template <typename R, bool BLK> struct Sim {
     mul_(F.RT, nTf, fw);
     make_frame(fw);
   }
+  // ---- patch-frame algebra for the block<->torso patch (BRS_PATCH_FRAME).  All points of a patch share ONE contact frame
+  // (n, t1, t2).  In FRAME coordinates, with positions r' taken from the torso origin and c' = the block centre,
+  //     acceleration of the torso's material point at r':  aT' + wT' x r'          (aT' = Fm x[0:3], wT' = Fm x[3:6])
+  //     ... of the block's:                                 aB' + wB' x (r' - c')   (aB' = Ph x[8:11], wB' = Ph x[11:14])
+  // so every point's three frame rows are  K(r') tau,  K(r) = [I | -[r]x],  tau = (Vp, Wp) = (aB' - aT' + c' x wB', wB' - wT'): the
+  // RELATIVE twist at the torso origin, a linear map of the 12 dofs that does not depend on the point.  The patch's contribution
+  // to H is therefore  T^T (sum_c K_c^T W_c K_c) T  with a 6x6 matrix Z accumulated per point (~45 FMAs) and ONE congruence per
+  // pass; the rows at x, and the wrench of the patch, are 6-vectors mapped once.  Per point the passes read 7 LDS words
+  // (r', An, Bt1, Bt2, D).  Record of patch slot k (words): 0-2 r', 3 An, 4 Bt1, 5 Bt2, 6 D; words 7-9 of slots 0-2 hold the
+  // frame axes in the TORSO frame (Fm rows), of slots 3-5 in the BLOCK frame (Ph rows); contact-frame slot 0 holds c'.
+  struct Patch { R Fm[9], Ph[9], c[3]; };
+  static_assert(!BRS_PATCH_FRAME || PATCH_MAX == 6, "the patch frame is parked in words 7-9 of patch slots 0-5");
+  static BRS_HD void patch_load(const Store<R>& st, Patch& Q) {
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) { Q.Fm[3 * k + j] = st.getc(k, 7 + j); Q.Ph[3 * k + j] = st.getc(3 + k, 7 + j); }
+    Q.c[0] = st.getf(0, 0); Q.c[1] = st.getf(0, 1); Q.c[2] = st.getf(0, 2);
+  }
+  // first point of a patch: frame from the unit normal nTf (torso frame), patch constants to LDS, and the CURRENT relative velocity
+  // twist (V0, W0) in frame coordinates for the reference accelerations of its points
+  static BRS_HD void patch_begin(Store<R>& st, const Frame& F, const ES& S, const R* nTf, Patch& Q, R* V0, R* W0) {
+    R fw[9];
+    world_frame(F, nTf, fw);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { mulT_(F.RT, fw + 3 * k, Q.Fm + 3 * k); mulT_(F.RB, fw + 3 * k, Q.Ph + 3 * k); }
+    R dW[3] = {-F.dTB[0], -F.dTB[1], -F.dTB[2]}, cT[3];  // x_B - x_T (world) -> torso frame -> frame coordinates
+    mulT_(F.RT, dW, cT);
+    mul_(Q.Fm, cT, Q.c);
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) { st.setc(k, 7 + j, Q.Fm[3 * k + j]); st.setc(3 + k, 7 + j, Q.Ph[3 * k + j]); }
+    st.setf(0, 0, Q.c[0]); st.setf(0, 1, Q.c[1]); st.setf(0, 2, Q.c[2]);
+    // velocities: S.v / S.bv are WORLD linear, S.w / S.bw BODY angular; frame coordinates of a world vector u: fw . u
+    R vT[3], vB[3], wT[3], wB[3], t[3];
+    mul_(fw, S.v, vT); mul_(fw, S.bv, vB); mul_(Q.Fm, S.w, wT); mul_(Q.Ph, S.bw, wB);
+    cross_(Q.c, wB, t);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { V0[k] = vB[k] - vT[k] + t[k]; W0[k] = wB[k] - wT[k]; }
+  }
+  static BRS_HD void add_patch_point(const Params<R>& P, Store<R>& st, Frame& F, const Patch& Q, const R* V0, const R* W0, const R* rT, R dist) {
+    if (F.nc >= PATCH_MAX) return;
+    const ContactClass<R>& c = P.cc[CC_BLOCK_ROBOT];
+    R r[3], t[3];
+    mul_(Q.Fm, rT, r);
+    cross_(W0, r, t);
+    const R vn = V0[0] + t[0], vt1 = V0[1] + t[1], vt2 = V0[2] + t[2];
+    const R imp = impedance_(c, dist);
+    const int k = F.nc;
+    st.setc(k, 0, r[0]); st.setc(k, 1, r[1]); st.setc(k, 2, r[2]);
+    st.setc(k, 3, -c.B * vn - c.K * imp * (dist - c.margin));
+    st.setc(k, 4, -c.B * c.mu * vt1);
+    st.setc(k, 5, -c.B * c.mu * vt2);
+    st.setc(k, 6, imp * rcp_((1 - imp) * c.cD));
+    F.nc++;
+  }
   // everything in the TORSO frame: block centre cB, block axes as columns of RTB = RT^T RB
   static BRS_HD void collide_coupled(const Params<R>& P, Store<R>& st, Frame& F, const ES& S) {
     const ContactClass<R>& c = P.cc[CC_BLOCK_ROBOT];
@@ -849,9 +911,16 @@ template <typename R, bool BLK> struct Sim {
 #pragma unroll
             for (int m = 0; m < 3; m++) pos[m] = (R)0.5 * (pA[m] + (m == i ? al : (R)0) + pB[m] + be * bj[m]);
             pos[2] += P.torso_cz;
+#if BRS_PATCH_FRAME
+            Patch Q;
+            R V0[3], W0[3];
+            patch_begin(st, F, S, L, Q, V0, W0);
+            add_patch_point(P, st, F, Q, V0, W0, pos, bestE);
+#else
             R fw[9];
             world_frame(F, L, fw);
             add_coupled(P, st, F, S, pos, fw, bestE, 0, false);
+#endif
           }
         } else {
           // face case.  Reference frame coordinates (u, v, g): u, v span the reference rectangle |u| <= ra, |v| <= rb, g is
@@ -1092,14 +1161,24 @@ template <typename R, bool BLK> struct Sim {
           }
           BRS_MARK("cc_insert");
           if (nkeep > 0) {
+#if BRS_PATCH_FRAME
+            Patch Q;
+            R V0[3], W0[3];
+            patch_begin(st, F, S, nrm, Q, V0, W0);  // one contact frame for the whole patch
+#else
             R fw[9];
             world_frame(F, nrm, fw);  // one contact frame for the whole patch
+#endif
             for (int r = 0; r < nkeep; r++) {
               const R u = scr[(3 * r) * st.stride], v = scr[(3 * r + 1) * st.stride], g = scr[(3 * r + 2) * st.stride];
               const R wv = half + (R)0.5 * g;
               R pos[3] = {A0[0] + u * A1[0] + v * A2[0] + wv * A3[0], A0[1] + u * A1[1] + v * A2[1] + wv * A3[1],
                           A0[2] + u * A1[2] + v * A2[2] + wv * A3[2] + P.torso_cz};
+#if BRS_PATCH_FRAME
+              add_patch_point(P, st, F, Q, V0, W0, pos, g);
+#else
               add_coupled(P, st, F, S, pos, fw, g, 0, r > 0);
+#endif
             }
           }
         }
@@ -1319,6 +1398,49 @@ template <typename R, bool BLK> struct Sim {
       }
     }
 
+    // relative acceleration twist of the patch at x, frame coordinates, taken at the torso origin (Sim::Patch)
+    static BRS_HD void patch_twist(const Patch& Q, const R* x, R* Vp, R* Wp) {
+      R aT[3], wT[3], aB[3], wB[3], t[3];
+      mul_(Q.Fm, x, aT); mul_(Q.Fm, x + 3, wT); mul_(Q.Ph, x + 8, aB); mul_(Q.Ph, x + 11, wB);
+      cross_(Q.c, wB, t);
+#pragma unroll
+      for (int k = 0; k < 3; k++) { Vp[k] = aB[k] - aT[k] + t[k]; Wp[k] = wB[k] - wT[k]; }
+    }
+    // rows of the whole block<->torso patch at x (and its wrench when FORCES), patch-frame algebra
+    template <bool FORCES>
+    static BRS_HD void passA_patch(const Params<R>& P, Store<R>& st, const Frame& F, Masks& M, const R* x, R& cst, R* l, R* fcon, bool& sm) {
+      Patch Q;
+      patch_load(st, Q);
+      R Vp[3], Wp[3], Ft[3] = {0, 0, 0}, Mt[3] = {0, 0, 0};
+      patch_twist(Q, x, Vp, Wp);
+      const R mu = P.cc[CC_BLOCK_ROBOT].mu;
+      for (int c = 0; c < F.nc; c++) {
+        const R r[3] = {st.getc(c, 0), st.getc(c, 1), st.getc(c, 2)};
+        const R An = st.getc(c, 3), Bt1 = st.getc(c, 4), Bt2 = st.getc(c, 5), D = st.getc(c, 6);
+        R t[3];
+        cross_(Wp, r, t);
+        int mk = rows_(Vp[0] + t[0] - An, mu * (Vp[1] + t[1]) - Bt1, mu * (Vp[2] + t[2]) - Bt2, D, cst, l, get4(M.hC, c), sm);
+        M.nC |= put4(mk, c);
+        if constexpr (FORCES) {
+          const R f[3] = {D * (l[0] + l[1] + l[2] + l[3]), D * mu * (l[0] - l[1]), D * mu * (l[2] - l[3])};  // frame coordinates, on the block
+          cross_(r, f, t);
+#pragma unroll
+          for (int k = 0; k < 3; k++) { Ft[k] += f[k]; Mt[k] += t[k]; }
+        }
+      }
+      if constexpr (FORCES) {  // wrench (at the torso origin) back to the dofs: -Fm^T on the torso, Ph^T on the block (moment about its centre)
+        R a[3], b[3], t[3];
+        mulT_(Q.Fm, Ft, a); mulT_(Q.Fm, Mt, b);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { fcon[k] -= a[k]; fcon[3 + k] -= b[k]; }
+        cross_(Q.c, Ft, t);
+        R mb[3] = {Mt[0] - t[0], Mt[1] - t[1], Mt[2] - t[2]};
+        mulT_(Q.Ph, Ft, a); mulT_(Q.Ph, mb, b);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { fcon[8 + k] += a[k]; fcon[11 + k] += b[k]; }
+      }
+    }
+
     // pass A: active-row masks at x (same = every mask equals the one H was built with) and, when FORCES, also the cost
     // and the constraint force J^T f.  The verify-only form is what the common path runs: at a point that reproduces its
     // active set the constraint force is M (x - a0) exactly, no need to accumulate it contact by contact.
@@ -1378,7 +1500,11 @@ template <typename R, bool BLK> struct Sim {
           }
         }
         Coupled C;
+#if BRS_PATCH_FRAME
+        if (F.nc > 0) passA_patch<FORCES>(P, st, F, M, x, cst, l, fcon, sm);
+#else
         for (int c = 0; c < F.nc; c++) passA_coupled<FORCES, false>(P, st, F, M, x, c, C, cst, l, fcon, sm);
+#endif
         if (sel_wheel_contact(F.sels)) passA_coupled<FORCES, true>(P, st, F, M, x, PATCH_MAX, C, cst, l, fcon, sm);
       }
       cost = cst;
@@ -1475,6 +1601,113 @@ template <typename R, bool BLK> struct Sim {
       M.hC |= put4(mk, c);
     }
 
+    // the whole block<->torso patch into H / rhs: Z = sum_c K_c^T W_c K_c (6x6, twist space, frame coordinates) and
+    // z = sum_c K_c^T rho_c per point, then ONE congruence per dof block:  torso dofs J = -K diag(Fm), block dofs J = K S diag(Ph)
+    // with the shift S = [[I, [c']x], [0, I]] from the block centre to the torso origin
+    static BRS_HD void assemble_patch(const Params<R>& P, Store<R>& st, const Frame& F, Masks& M, bool first, uint32_t srcC,
+                                      V2<R>* H, V2<R>* rhs2, const R* x) {
+      Patch Q;
+      patch_load(st, Q);
+      R Vp[3] = {0, 0, 0}, Wp[3] = {0, 0, 0};
+      if (first) patch_twist(Q, x, Vp, Wp);  // rows of contacts without a hint are evaluated at the warm start
+      const R mu = P.cc[CC_BLOCK_ROBOT].mu;
+      R Za = 0, Zp = 0, Zq = 0, Zb = 0, Zc = 0;  // Zvv = [[a, p, q], [p, b, 0], [q, 0, c]] (the sum of the points' 3x3 weights)
+      R Zvw[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Zww[6] = {0, 0, 0, 0, 0, 0}, zv[3] = {0, 0, 0}, zw[3] = {0, 0, 0};  // Zww: 00 10 11 20 21 22
+      for (int c = 0; c < F.nc; c++) {
+        const R rx = st.getc(c, 0), ry = st.getc(c, 1), rz = st.getc(c, 2);
+        const R An = st.getc(c, 3), Bt1 = st.getc(c, 4), Bt2 = st.getc(c, 5), D = st.getc(c, 6);
+        int mk = get4(srcC, c);
+        if (first && !(BRS_MASK_HINT && c < F.pnc)) {
+          const R cn = Vp[0] + (Wp[1] * rz - Wp[2] * ry) - An, c1 = mu * (Vp[1] + (Wp[2] * rx - Wp[0] * rz)) - Bt1,
+                  c2 = mu * (Vp[2] + (Wp[0] * ry - Wp[1] * rx)) - Bt2;
+          mk = (cn + c1 < 0 ? 1 : 0) | (cn - c1 < 0 ? 2 : 0) | (cn + c2 < 0 ? 4 : 0) | (cn - c2 < 0 ? 8 : 0);
+        }
+        M.hC |= put4(mk, c);
+        const R b0 = (mk & 1) ? (R)1 : (R)0, b1 = (mk & 2) ? (R)1 : (R)0, b2 = (mk & 4) ? (R)1 : (R)0, b3 = (mk & 8) ? (R)1 : (R)0;
+        const R Dm = D * mu, Dmm = Dm * mu;
+        const R a = D * (b0 + b1 + b2 + b3), p = Dm * (b0 - b1), q = Dm * (b2 - b3), b = Dmm * (b0 + b1), cc = Dmm * (b2 + b3);
+        // rho = sum_k act_k D aref_k (row weights in frame coordinates), as in contact_into
+        const R rn = a * An + D * ((b0 - b1) * Bt1 + (b2 - b3) * Bt2), r1 = p * An + Dm * (b0 + b1) * Bt1, r2 = q * An + Dm * (b2 + b3) * Bt2;
+        Za += a; Zp += p; Zq += q; Zb += b; Zc += cc;
+        // U = W [r]x, columns W (0, z, -y), W (-z, 0, x), W (y, -x, 0)
+        const R u00 = p * rz - q * ry, u10 = b * rz, u20 = -cc * ry;
+        const R u01 = q * rx - a * rz, u11 = -p * rz, u21 = cc * rx - q * rz;
+        const R u02 = a * ry - p * rx, u12 = p * ry - b * rx, u22 = q * ry;
+        // K^T W K = [[W, -U], [-U^T, -[r]x U]]
+        Zvw[0] -= u00; Zvw[1] -= u01; Zvw[2] -= u02; Zvw[3] -= u10; Zvw[4] -= u11; Zvw[5] -= u12; Zvw[6] -= u20; Zvw[7] -= u21; Zvw[8] -= u22;
+        // ([r]x U)[i][j] = (r x U[:, j])_i ; lower triangle only
+        Zww[0] -= ry * u20 - rz * u10;
+        Zww[1] -= rz * u00 - rx * u20; Zww[2] -= rz * u01 - rx * u21;
+        Zww[3] -= rx * u10 - ry * u00; Zww[4] -= rx * u11 - ry * u01; Zww[5] -= rx * u12 - ry * u02;
+        zv[0] += rn; zv[1] += r1; zv[2] += r2;
+        zw[0] += ry * r2 - rz * r1; zw[1] += rz * rn - rx * r2; zw[2] += rx * r1 - ry * rn;
+      }
+      // 3x3 blocks as full matrices
+      const R Zvv[9] = {Za, Zp, Zq, Zp, Zb, 0, Zq, 0, Zc};
+      const R Zw[9] = {Zww[0], Zww[1], Zww[3], Zww[1], Zww[2], Zww[4], Zww[3], Zww[4], Zww[5]};
+      // shift to the block centre: Y10 = -[c]x Zvv + Zvw^T, Y11 = -[c]x Zvw + Zww, B11 = Y10 [c]x + Y11 (symmetric)
+      const R cx = Q.c[0], cy = Q.c[1], cz = Q.c[2];
+      R Y10[9], Y11[9], B11[9];
+#pragma unroll
+      for (int j = 0; j < 3; j++) {  // column j of -[c]x X = -(c x X[:, j])
+        const R v0 = Zvv[j], v1 = Zvv[3 + j], v2 = Zvv[6 + j];
+        Y10[j] = -(cy * v2 - cz * v1) + Zvw[3 * j]; Y10[3 + j] = -(cz * v0 - cx * v2) + Zvw[3 * j + 1]; Y10[6 + j] = -(cx * v1 - cy * v0) + Zvw[3 * j + 2];
+        const R w0 = Zvw[j], w1 = Zvw[3 + j], w2 = Zvw[6 + j];
+        Y11[j] = -(cy * w2 - cz * w1) + Zw[j]; Y11[3 + j] = -(cz * w0 - cx * w2) + Zw[3 + j]; Y11[6 + j] = -(cx * w1 - cy * w0) + Zw[6 + j];
+      }
+#pragma unroll
+      for (int i = 0; i < 3; i++) {  // row i of X [c]x = (X[i,:] x c)... (X [c]x)[i][j] = sum_k X[i][k] [c]x[k][j] = (X[i,:] x c)_j with the sign below
+        const R y0 = Y10[3 * i], y1 = Y10[3 * i + 1], y2 = Y10[3 * i + 2];
+        // [c]x = [[0, -cz, cy], [cz, 0, -cx], [-cy, cx, 0]]
+        B11[3 * i] = y1 * cz - y2 * cy + Y11[3 * i]; B11[3 * i + 1] = y2 * cx - y0 * cz + Y11[3 * i + 1]; B11[3 * i + 2] = y0 * cy - y1 * cx + Y11[3 * i + 2];
+      }
+      // congruences A^T X B into the lower triangle of H (rows ra.., columns ca..): out[i][j] = sum_{m,n} A[m][i] X[m][n] B[n][j]
+      auto cong = [&](const R* A, const R* X, const R* B, R sgn, auto put) {
+        R XB[9];
+#pragma unroll
+        for (int m = 0; m < 3; m++)
+#pragma unroll
+          for (int j = 0; j < 3; j++) XB[3 * m + j] = X[3 * m] * B[j] + X[3 * m + 1] * B[3 + j] + X[3 * m + 2] * B[6 + j];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+          for (int j = 0; j < 3; j++) put(i, j, sgn * (A[i] * XB[j] + A[3 + i] * XB[3 + j] + A[6 + i] * XB[6 + j]));
+      };
+      R ZvwT[9];
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) ZvwT[3 * i + j] = Zvw[3 * j + i];
+#define BRS_HADD(ra, ca) [&](int i, int j, R v) { if ((ra) + i >= (ca) + j) hadd(H, (ra) + i, (ca) + j, v); }
+      cong(Q.Fm, Zvv, Q.Fm, (R)1, BRS_HADD(0, 0));     // torso lin-lin
+      cong(Q.Fm, ZvwT, Q.Fm, (R)1, BRS_HADD(3, 0));    // torso ang-lin  (Zwv = Zvw^T)
+      cong(Q.Fm, Zw, Q.Fm, (R)1, BRS_HADD(3, 3));      // torso ang-ang
+      cong(Q.Ph, Zvv, Q.Ph, (R)1, BRS_HADD(8, 8));     // block lin-lin
+      cong(Q.Ph, Y10, Q.Ph, (R)1, BRS_HADD(11, 8));    // block ang-lin
+      cong(Q.Ph, B11, Q.Ph, (R)1, BRS_HADD(11, 11));   // block ang-ang
+      cong(Q.Ph, Zvv, Q.Fm, (R)-1, BRS_HADD(8, 0));    // block lin x torso lin    (J_T = -K diag(Fm): minus)
+      cong(Q.Ph, Zvw, Q.Fm, (R)-1, BRS_HADD(8, 3));    // block lin x torso ang
+      cong(Q.Ph, Y10, Q.Fm, (R)-1, BRS_HADD(11, 0));   // block ang x torso lin
+      cong(Q.Ph, Y11, Q.Fm, (R)-1, BRS_HADD(11, 3));   // block ang x torso ang
+#undef BRS_HADD
+      // rhs += J^T rho: torso -diag(Fm^T) z, block diag(Ph^T) S^T z with S^T z = (zv, zw - c x zv)
+      R a3[3], b3[3], t[3];
+      mulT_(Q.Fm, zv, a3); mulT_(Q.Fm, zw, b3);
+#pragma unroll
+      for (int k = 0; k < 3; k++) { radd(rhs2, k, -a3[k]); radd(rhs2, 3 + k, -b3[k]); }
+      cross_(Q.c, zv, t);
+      R zb[3] = {zw[0] - t[0], zw[1] - t[1], zw[2] - t[2]};
+      mulT_(Q.Ph, zv, a3); mulT_(Q.Ph, zb, b3);
+#pragma unroll
+      for (int k = 0; k < 3; k++) { radd(rhs2, 8 + k, a3[k]); radd(rhs2, 11 + k, b3[k]); }
+    }
+    static BRS_HD void hadd(V2<R>* H, int a, int b, R v) {
+      if (b & 1) H[hp(a, b / 2)].y += v; else H[hp(a, b / 2)].x += v;
+    }
+    static BRS_HD void radd(V2<R>* rhs2, int i, R v) {
+      if (i & 1) rhs2[i / 2].y += v; else rhs2[i / 2].x += v;
+    }
+
     // assemble H = M + sum_active D j j^T and rhs = M a0 + sum_active D aref j  (both on the packed-pair layout)
     static BRS_HD void assemble(const Params<R>& P, Store<R>& st, const Frame& F, Masks& M, const R* x, const R* a0, bool first,
                                 V2<R>* H, V2<R>* rhs2) {
@@ -1535,7 +1768,11 @@ template <typename R, bool BLK> struct Sim {
         }
         Coupled C;
         BRS_MARK("asm_patch_loop");
+#if BRS_PATCH_FRAME
+        if (F.nc > 0) assemble_patch(P, st, F, M, first, srcC, H, rhs2, x);
+#else
         for (int c = 0; c < F.nc; c++) assemble_coupled<false>(P, st, F, M, first, srcC, c, C, H, rhs2, x2);
+#endif
         BRS_MARK("asm_wheel_contact");
         if (sel_wheel_contact(F.sels)) assemble_coupled<true>(P, st, F, M, first, srcC, PATCH_MAX, C, H, rhs2, x2);
         BRS_MARK("asm_done");

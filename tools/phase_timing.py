@@ -1,13 +1,15 @@
 #!/usr/bin/env python3
 """Diagnostic: per-phase wave cycles of the step kernel (needs a -DBRS_TIMING build; run on the GPU box).
-    BRS_EXTRA_HIPCC_FLAGS=-DBRS_TIMING python tools/phase_timing.py [Env03-v2]"""
+    BRS_EXTRA_HIPCC_FLAGS=-DBRS_TIMING python tools/phase_timing.py [Env03-v2]
+    BRS_HIP_LIB=ab/libbrs_hip_timing.so python tools/phase_timing.py [Env03-v2]     (prebuilt: tools/ab_build.py timing -DBRS_TIMING)"""
 import ctypes as C, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("BRS_EXTRA_HIPCC_FLAGS", "-DBRS_TIMING")
 from balance_robot_mujoco_rl_amd import _lib
-_lib.build(force=True)
+if not os.environ.get("BRS_HIP_LIB"):   # (or point BRS_HIP_LIB at a prebuilt -DBRS_TIMING variant: tools/ab_build.py timing -DBRS_TIMING)
+    os.environ.setdefault("BRS_EXTRA_HIPCC_FLAGS", "-DBRS_TIMING")
+    _lib.build(force=True)
 from balance_robot_mujoco_rl_amd import BatchedSim
 env = sys.argv[1] if len(sys.argv) > 1 else "Env03-v2"
 n = 65536
