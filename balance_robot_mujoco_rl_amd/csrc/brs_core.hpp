@@ -75,12 +75,17 @@ __device__ __forceinline__ unsigned long long* brs_tim_slots() {  // 16 x u64 pe
 #ifndef BRS_PATCH_FRAME
 #define BRS_PATCH_FRAME 1
 #endif
+// clip candidates of the box-box patch parked at fixed LDS words and walked by bit scan (1) or rank-scattered (0)
+#ifndef BRS_FIXED_SCATTER
+#define BRS_FIXED_SCATTER 0
+#endif
 
 namespace brs {
 
 #if defined(BRS_STATS) && !defined(__HIP_DEVICE_COMPILE__)
 struct Stats { long substeps, solves[3], iters[3], passA[3], backtracks[3]; int last_iters[3]; long hist[17], trips;
-               long cp_calls, cp_reach, cp_torso, cp_wheel, cp_nc, cp_tight_torso, cp_tight_wheel, nfr_hist[9], nfb_hist[5], nc_hist[8]; };
+               long cp_calls, cp_reach, cp_torso, cp_wheel, cp_nc, cp_tight_torso, cp_tight_wheel, nfr_hist[9], nfb_hist[5], nc_hist[8];
+               long flip_hist[2][9], trips_alt; int first_single; };  // rows that differ from the assembled set after the 1st / a later iteration's verify pass
 inline Stats& stats() { static thread_local Stats s{}; return s; }
 #define BRS_STAT(expr) do { expr; } while (0)
 #else
@@ -1149,9 +1154,18 @@ template <typename R, bool BLK> struct Sim {
           }
           BRS_MARK("cc_scatter");
           const int nkeep = (int)__builtin_popcount(keep);
+          R* scr = st.base + (SLOT_ROBOT * SLOT_WORDS) * st.stride;
+#if BRS_FIXED_SCATTER
+          // all 16 candidates parked at FIXED words of the (not yet written) robot<->floor slot region -- 48 stores at immediate
+          // offsets, no address arithmetic; the insertion loop walks `keep` by bit scan (ascending candidate index = rank order)
+          static_assert(16 * 3 <= N_ROBOT_SLOTS * SLOT_WORDS, "the candidate scratch must fit the robot<->floor slot region");
+#pragma unroll
+          for (int q = 0; q < 16; q++) {
+            scr[(3 * q) * st.stride] = cu_[q]; scr[(3 * q + 1) * st.stride] = cv_[q]; scr[(3 * q + 2) * st.stride] = gq[q];
+          }
+#else
           // compaction through the lane's LDS column: kept candidate with rank r -> scratch words 3r .. 3r+2 of the (not yet
           // written) robot<->floor slot region, everything else -> a dump slot; the insertion loop then reads by rank
-          R* scr = st.base + (SLOT_ROBOT * SLOT_WORDS) * st.stride;
 #pragma unroll
           for (int q = 0; q < 16; q++) {
             const bool kq = ((keep >> q) & 1u) != 0;
@@ -1159,6 +1173,7 @@ template <typename R, bool BLK> struct Sim {
             R* dst = scr + (3 * (kq ? rank : PATCH_MAX)) * st.stride;
             dst[0] = cu_[q]; dst[st.stride] = cv_[q]; dst[2 * st.stride] = gq[q];
           }
+#endif
           BRS_MARK("cc_insert");
           if (nkeep > 0) {
 #if BRS_PATCH_FRAME
@@ -1169,8 +1184,17 @@ template <typename R, bool BLK> struct Sim {
             R fw[9];
             world_frame(F, nrm, fw);  // one contact frame for the whole patch
 #endif
+#if BRS_FIXED_SCATTER
+            uint32_t walk = keep;
+#endif
             for (int r = 0; r < nkeep; r++) {
+#if BRS_FIXED_SCATTER
+              const int qi = __builtin_ctz(walk);
+              walk &= walk - 1u;
+              const R u = scr[(3 * qi) * st.stride], v = scr[(3 * qi + 1) * st.stride], g = scr[(3 * qi + 2) * st.stride];
+#else
               const R u = scr[(3 * r) * st.stride], v = scr[(3 * r + 1) * st.stride], g = scr[(3 * r + 2) * st.stride];
+#endif
               const R wv = half + (R)0.5 * g;
               R pos[3] = {A0[0] + u * A1[0] + v * A2[0] + wv * A3[0], A0[1] + u * A1[1] + v * A2[1] + wv * A3[1],
                           A0[2] + u * A1[2] + v * A2[2] + wv * A3[2] + P.torso_cz};
@@ -1813,6 +1837,8 @@ template <typename R, bool BLK> struct Sim {
       } else
         passA<true>(P, st, F, M, xn, a0, ct, ft, same);
       BRS_TOC(6);
+      BRS_STAT(if (!same) { int nf_ = __builtin_popcount(M.nR ^ M.hR) + __builtin_popcount(M.nB ^ M.hB) + __builtin_popcount(M.nC ^ M.hC);
+                            stats().flip_hist[it == 0 ? 0 : 1][nf_ > 8 ? 8 : nf_]++; if (it == 0) stats().first_single = nf_ == 1; });
       BRS_MARK("iter_tail");
       bool full = true;
       // pure active-set iteration for the first sweeps (it terminates at once in ~97% of the substeps); if it has not
@@ -1940,7 +1966,7 @@ template <typename R, bool BLK> struct Sim {
 #pragma unroll
       for (int i = 0; i < NV; i++) { S.a[i] = F.a0[i]; C.fcon[i] = 0; }
     }
-    BRS_STAT(stats().last_iters[0] = 0; if (!C.conv) stats().solves[0]++);
+    BRS_STAT(stats().last_iters[0] = 0; stats().first_single = 0; if (!C.conv) stats().solves[0]++);
     BRS_STAT(stats().nfr_hist[F.nfr]++; stats().nfb_hist[F.nfb]++; stats().nc_hist[F.nc]++);
   }
   static BRS_HD void sub_iter(const Params<R>& P, Store<R>& st, ES& S, SubCtx& C) {
@@ -2014,7 +2040,8 @@ template <typename R, bool BLK> struct Sim {
     for (int i_ = 0; i_ < 4; i_++) BRS_PIN(S.q[i_]);
     BRS_PIN(S.ww[0]); BRS_PIN(S.ww[1]);
     BRS_TOC(7);
-    BRS_STAT(int li = stats().last_iters[0]; stats().hist[li > 16 ? 16 : li]++; stats().trips += li > 1 ? li : 1; stats().substeps++);
+    BRS_STAT(int li = stats().last_iters[0]; stats().hist[li > 16 ? 16 : li]++; stats().trips += li > 1 ? li : 1; stats().substeps++;
+             stats().trips_alt += (li == 2 && stats().first_single) ? 1 : (li > 1 ? li : 1));  // if a single-row flip were repaired inside the trip
     BRS_MARK("end_done");
   }
   // un-flattened form (one lane at a time: host tests, single substeps)
