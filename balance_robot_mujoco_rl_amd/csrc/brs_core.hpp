@@ -77,8 +77,14 @@ __device__ __forceinline__ unsigned long long* brs_tim_slots() {  // 16 x u64 pe
 #endif
 // clip candidates of the box-box patch parked at fixed LDS words and walked by bit scan (1) or rank-scattered (0)
 #ifndef BRS_FIXED_SCATTER
-#define BRS_FIXED_SCATTER 0
+#define BRS_FIXED_SCATTER 1
 #endif
+// (Tried and not kept, round 3: the robot<->floor contacts in the same frame algebra as the patch -- they all share the world-aligned
+// frame, so they can accumulate one 8x8 matrix in (frame-coordinate twist, two wheel rates) and enter H by one congruence: 840
+// instead of ~1,400 instructions per trip on paper, but scalar and serially dependent where contact_into is packed and
+// independent: -1.5 % Env03-v2, -1.8 % Env03-v1, +0.3 % Env01-v2 on one box.  Also not kept: the patch's ten 3x3 congruences as
+// ~320 v_pk_fma_f32 on row pairs in H's own layout instead of ~540 scalar FMAs: +0.5 % / -1.3 % (v2 / v1), 50 more registers.
+// profiles/r03_ab_experiments.json.)
 
 namespace brs {
 
@@ -1725,6 +1731,7 @@ template <typename R, bool BLK> struct Sim {
 #pragma unroll
       for (int k = 0; k < 3; k++) { radd(rhs2, 8 + k, a3[k]); radd(rhs2, 11 + k, b3[k]); }
     }
+
     static BRS_HD void hadd(V2<R>* H, int a, int b, R v) {
       if (b & 1) H[hp(a, b / 2)].y += v; else H[hp(a, b / 2)].x += v;
     }
