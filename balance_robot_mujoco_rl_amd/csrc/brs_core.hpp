@@ -2062,8 +2062,28 @@ template <typename R, bool BLK> struct Sim {
   // =================================================================================== env logic
   // (restates envs/RobotBaseEnv.py:127-246, env01_v2.py:16-71, env03_v1.py:26-114, env03_v2.py:14-59;
   //  pinned through oracle/ by tests/golden/envlogic.json)
+  // scipy Rotation.from_quat([x, y, z, w]).as_euler('xyz') -> angles[0] (pitch), angles[2] (yaw): envs/RobotBaseEnv.py:127-135, :177-184.
+  // scipy >= 1.10 (the reference pins 1.14.1) computes them from the quaternion (Bernardes & Viollet 2022): a = w - y, b = x + z,
+  // c = w + y, d = z - x, second angle 2 atan2(hypot(c, d), hypot(a, b)) - pi/2, first/third = atan2(b, a) -/+ atan2(d, c) -- equal
+  // to the two atan2 forms below except within 1e-7 rad of GIMBAL LOCK (the wheel axis vertical), where scipy sets the third
+  // angle to 0 and puts the whole rotation about the vertical into the first: pitch = 2 atan2(b, a) (second angle -pi/2) or
+  // -2 atan2(d, c) (+pi/2), wrapped to [-pi, pi].  The test on the ratio of the two hypotenuses is taken in fp64 (it resolves
+  // 5e-8); pinned by tests/golden/envlogic.json: pitch_yaw_gimbal, generated from the reference's own methods with the real scipy.
   static BRS_HD void pitch_yaw(const double* xq, R& pitch, R& yaw) {
     if (xq[0] == 0.0) { pitch = 0; yaw = 0; return; }
+    {
+      const double a = xq[0] - xq[2], b = xq[1] + xq[3], c = xq[0] + xq[2], d = xq[3] - xq[1];
+      const double ab2 = a * a + b * b, cd2 = c * c + d * d, k2 = 2.5e-15;  // tan(1e-7 / 2)^2
+      const bool lock_lo = cd2 <= k2 * ab2, lock_hi = ab2 <= k2 * cd2;
+      if (lock_lo || lock_hi) {  // measure-zero in a simulation; a wave skips this block
+        R p = lock_lo ? (R)2 * atan2_((R)b, (R)a) : (R)-2 * atan2_((R)d, (R)c);
+        const R PI = (R)3.14159265358979323846;
+        if (p > PI) p -= 2 * PI;
+        if (p < -PI) p += 2 * PI;
+        pitch = p; yaw = 0;
+        return;
+      }
+    }
     R w = (R)xq[0], x = (R)xq[1], y = (R)xq[2], z = (R)xq[3];
     R n2 = w * w + x * x + y * y + z * z, s = 2 * rcp_(n2);  // scipy normalises; atan2 is scale-free
     pitch = atan2_(s * (y * z + w * x), 1 - s * (x * x + y * y));

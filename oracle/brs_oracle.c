@@ -1193,14 +1193,27 @@ static double snext(stream_t* s) {
   return (double)(s->buf[s->pos++] >> 8) * (1.0 / 16777216.0);
 }
 
-/* RobotBaseEnv.py:127-135 / :177-184: scipy Rotation.from_quat(x,y,z,w).as_euler('xyz') -> [0] pitch, [2] yaw */
+/* RobotBaseEnv.py:127-135 / :177-184: scipy Rotation.from_quat(x,y,z,w).as_euler('xyz') -> [0] pitch, [2] yaw.
+   scipy (un-vendored dependency, pinned at 1.14.1 by conda-environment.yaml:10) computes Euler angles from the quaternion by the
+   published algorithm of Bernardes & Viollet (2022), restated here for the extrinsic sequence 'xyz' (i, j, k = 0, 1, 2; sign +1):
+   second angle from the two hypotenuses, first/third from a half sum and a half difference, and within eps = 1e-7 of gimbal lock
+   the third angle is set to zero.  Checked against scipy itself through tests/golden/envlogic.json (pitch_yaw, pitch_yaw_gimbal). */
 void bo_pitch_yaw(const double xq[4], double* pitch, double* yaw) {
   if (xq[0] == 0) { *pitch = 0; *yaw = 0; return; }
   double q[4] = {xq[0], xq[1], xq[2], xq[3]};
   normalize4(q);
-  double w = q[0], x = q[1], y = q[2], z = q[3];
-  *pitch = atan2(2 * (y * z + w * x), 1 - 2 * (x * x + y * y));
-  *yaw = atan2(2 * (x * y + w * z), 1 - 2 * (y * y + z * z));
+  const double w = q[0], x = q[1], y = q[2], z = q[3], eps = 1e-7;
+  const double a = w - y, b = x + z, c = y + w, d = z - x;
+  const double second = 2 * atan2(hypot(c, d), hypot(a, b));
+  const double hs = atan2(b, a), hd = atan2(d, c);
+  double first, third;
+  if (fabs(second) <= eps) { first = 2 * hs; third = 0; }             /* second angle -pi/2 */
+  else if (fabs(second - PI) <= eps) { first = -2 * hd; third = 0; }  /* second angle +pi/2 (extrinsic: minus) */
+  else { first = hs - hd; third = hs + hd; }
+  if (first < -PI) first += 2 * PI; else if (first > PI) first -= 2 * PI;
+  if (third < -PI) third += 2 * PI; else if (third > PI) third -= 2 * PI;
+  *pitch = first;
+  *yaw = third;
 }
 /* env01_v2.py:16-20: every get_pitch() call adds a fresh U(-0.025,0.025) sample */
 static double get_pitch(const model_t* m, env_t* e, stream_t* s) {

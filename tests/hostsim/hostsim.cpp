@@ -168,4 +168,9 @@ void hs_step_stub(void* h, int e, const float* a, const double* qp, const double
                   uint8_t* te, uint8_t* tr, double* ctrl) { ((IHost*)h)->step_stub(e, a, qp, qv, xq, xp, o, r, te, tr, ctrl); }
 void hs_script(void* h, int e, const double* u, int n) { ((IHost*)h)->script(e, u, n); }
 int hs_script_remaining(void* h, int e) { return ((IHost*)h)->script_remaining(e); }
+// the kernel source's get_pitch / get_yaw core on one accessor quaternion (float or double instantiation)
+void hs_pitch_yaw(const double* xq, int use_double, double* pitch, double* yaw) {
+  if (use_double) { double p, y; Sim<double, false>::pitch_yaw(xq, p, y); *pitch = p; *yaw = y; }
+  else { float p, y; Sim<float, false>::pitch_yaw(xq, p, y); *pitch = p; *yaw = y; }
+}
 }

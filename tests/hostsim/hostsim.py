@@ -26,6 +26,7 @@ def lib():
                                hs_reset=[vp, u8p, fp], hs_step=[vp, fp, fp, fp, u8p, u8p, fp],
                                hs_script=[vp, C.c_int, dp, C.c_int], hs_step_stub=[vp, C.c_int, fp, dp, dp, dp, dp, fp, fp, u8p, u8p, dp], hs_script_remaining=[vp, C.c_int]).items():
             getattr(L, name).argtypes = args
+        L.hs_pitch_yaw.argtypes = [dp, C.c_int, dp, dp]
         _lib = L
     return _lib
 
@@ -117,3 +118,11 @@ class HostSim:
 
     def script_remaining(self, env):
         return self.L.hs_script_remaining(self.h, env)
+
+
+def pitch_yaw(xquat, double=False):
+    """Sim<R>::pitch_yaw of the kernel source on one accessor quaternion (w, x, y, z)"""
+    q = np.ascontiguousarray(xquat, dtype=np.float64)
+    p, y = C.c_double(), C.c_double()
+    lib().hs_pitch_yaw(_p(q, C.c_double), int(double), C.byref(p), C.byref(y))
+    return p.value, y.value

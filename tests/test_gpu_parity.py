@@ -409,6 +409,37 @@ def test_masked_reset_touches_only_the_masked_envs():
     sim.close(); orc.close()
 
 
+def test_pitch_on_the_device_incl_gimbal_lock():
+    """get_pitch on the DEVICE build (fast-math, fp64 lock test, v_rcp) against the reference's own get_pitch with the real scipy
+    (tests/golden/envlogic.json: pitch_yaw, pitch_yaw_gimbal): one 20-us substep of free fall from the fixture's quaternion, so the
+    accessor pose the observation reads IS that quaternion.  Within 1e-7 rad of gimbal lock scipy folds the rotation about the
+    vertical into the pitch; the env then terminates or not on that number."""
+    import json
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "envlogic.json")))
+    cases = g["pitch_yaw"] + [c for c in g["pitch_yaw_gimbal"] if c["yaw"] == 0.0]
+    cases = [c for c in cases if c["xquat"][0] != 0.0]
+    n = len(cases)
+    import torch
+    from balance_robot_mujoco_rl_amd import BatchedSim
+    sim = BatchedSim("Env01-v1", n, device=0, seed=1, auto_reset=False, obs_noise=False, substeps=1)
+    sim.reset()
+    qpos = np.zeros((n, 9)); qpos[:, 2] = 1.0
+    qpos[:, 3:7] = np.array([c["xquat"] for c in cases])
+    sim.set_state(qpos, np.zeros((n, 8)), np.zeros((n, 8)), np.zeros(n))
+    obs, _, te, _, _ = sim.step(torch.zeros((n, 2), device="cuda"))
+    torch.cuda.synchronize()
+    pitch = obs.cpu().numpy()[:, 0] * 0.25
+    want = np.array([c["pitch"] for c in cases])
+    d = np.abs((pitch - want + np.pi) % (2 * np.pi) - np.pi)
+    locked = np.array([c in g["pitch_yaw_gimbal"] for c in cases])
+    print(f"device pitch vs scipy: max |d| {d.max():.3g} over {n} poses ({int(locked.sum())} at gimbal lock)")
+    assert d.max() < 5e-6, (int(d.argmax()), cases[int(d.argmax())], float(pitch[d.argmax()]))
+    lim = 50.0 * np.pi / 180.0
+    clear = np.abs(np.abs(want) - lim) > 1e-4
+    assert np.array_equal(te.cpu().numpy().astype(bool)[clear], (np.abs(want) > lim)[clear])
+    sim.close()
+
+
 def test_full_size_properties():
     """BASELINE size (65,536 x Env03-v2): size-independent invariants after a random-policy rollout"""
     import torch

@@ -124,3 +124,21 @@ def test_sequences_f3(golden, idx, double):
             np.testing.assert_allclose(obs[1], ref[1], rtol=1e-4, atol=1e-8 if double else 3e-4)
         assert abs(rew - st["reward"]) < (1e-6 if double else 2e-4) * max(1.0, abs(st["reward"])), (k, rew, st["reward"])
         assert abs(h.get_aux()[0, 13] - st["extras"]["target_wheel_speed"]) < 1e-4, k
+
+
+@pytest.mark.parametrize("double", [False, True])
+def test_pitch_yaw_goldens_incl_gimbal_lock(golden, double):
+    """Sim<R>::pitch_yaw of the kernel source against the reference's get_pitch / get_yaw (real scipy), including the poses within
+    1e-7 rad of gimbal lock where scipy zeroes the yaw"""
+    from tests.hostsim import hostsim as H
+    tol = 1e-9 if double else 2e-6
+    cases = golden["pitch_yaw"] + golden["pitch_yaw_gimbal"]
+    if not double:  # close to the lock but outside it the two atan2 arguments shrink to ~|offset|: fp32 resolves the angles to
+        # ~1e-7 / |offset| only (nothing new: the env logic evaluates the pitch in fp32) -- in float, check the locked poses and
+        # the ordinary ones
+        cases = golden["pitch_yaw"] + [c for c in golden["pitch_yaw_gimbal"] if c["yaw"] == 0.0]
+    for c in cases:
+        p, y = H.pitch_yaw(c["xquat"], double=double)
+        dp = abs((p - c["pitch"] + np.pi) % (2 * np.pi) - np.pi)
+        dy = abs((y - c["yaw"] + np.pi) % (2 * np.pi) - np.pi)
+        assert dp < tol and dy < tol, (c, p, y)

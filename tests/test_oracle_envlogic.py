@@ -29,6 +29,22 @@ def test_pitch_yaw(golden):
         assert abs(y - c["yaw"]) < 1e-12, c
 
 
+def _angle_diff(a, b):
+    return abs((a - b + np.pi) % (2 * np.pi) - np.pi)
+
+
+def test_pitch_yaw_at_gimbal_lock(golden):
+    """scipy's as_euler('xyz') within 1e-7 rad of gimbal lock (wheel axis vertical) zeroes the yaw and folds the rotation about the
+    vertical into the pitch; the vectors come from the reference's get_pitch / get_yaw with the real scipy (tools/gen_golden.py)"""
+    locked = 0
+    for c in golden["pitch_yaw_gimbal"]:
+        p, y = O.pitch_yaw(c["xquat"])
+        locked += c["yaw"] == 0.0 and abs(c["pitch"]) > 1e-3
+        # (angles are compared on the circle: at +-pi the wrap is decided by the last bit)
+        assert _angle_diff(p, c["pitch"]) < 1e-9 and _angle_diff(y, c["yaw"]) < 1e-9, (c, p, y)
+    assert locked >= 12  # the fixture does contain locked poses
+
+
 def test_reward(golden):
     o = O.Oracle("Env01-v1", 1)
     for c in golden["reward"]:

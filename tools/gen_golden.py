@@ -256,6 +256,21 @@ def main():
         env.data.xquat_robot[:] = q
         cases.append(dict(xquat=L(q), pitch=float(env.get_pitch()), yaw=float(env.get_yaw())))
     out["pitch_yaw"] = cases
+    # gimbal lock of as_euler('xyz') (the wheel axis vertical: second angle +-pi/2): within 1e-7 rad scipy zeroes the yaw and puts
+    # the whole rotation about the vertical into the pitch (and warns); just outside it does not
+    import warnings
+    cases = []
+    from scipy.spatial.transform import Rotation as _Rot
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for sgn in (1.0, -1.0):
+            for off in (0.0, 1e-9, 3e-8, -3e-8, 3e-7, -3e-7, 1e-5, 1e-3):
+                for a, c in ((0.3, 0.7), (-1.2, 2.0), (2.9, 1.5), (0.0, 0.0)):
+                    x, y, z, w = _Rot.from_euler("xyz", [a, sgn * (np.pi / 2 - off), c]).as_quat()
+                    q = np.array([w, x, y, z]) * (1.0 if (a, c) != (2.9, 1.5) else 1.7)  # one family un-normalised
+                    env.data.xquat_robot[:] = q
+                    cases.append(dict(xquat=L(q), pitch=float(env.get_pitch()), yaw=float(env.get_yaw())))
+    out["pitch_yaw_gimbal"] = cases
 
     # ---------------------------------------------------------------- (2) reward (no-noise class)
     cases = []
