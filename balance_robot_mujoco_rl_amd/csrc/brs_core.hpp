@@ -1483,10 +1483,27 @@ template <typename R, bool BLK> struct Sim {
 #pragma unroll
       for (int i = 0; i < NN; i++) fcon[i] = 0;
       bool sm = true;
+      // Env01 family: the record of the NEXT contact is requested from LDS before this one is evaluated -- a lone wave cannot hide
+      // the ~100-cycle return behind another wave's work (+2.5 % Env01-v2, same box).  Not for Env03: the 7 live words cost it
+      // 30 more SGPR spills and the gain is gone (profiles/r03_ab_experiments.json).
+      constexpr bool PF = !BLK;
+      R nx_[SLOT_WORDS];
+      if constexpr (PF) {
+#pragma unroll
+        for (int w_ = 0; w_ < SLOT_WORDS; w_++) nx_[w_] = st.get(SLOT_ROBOT, w_);
+      }
       for (int c = 0; c < F.nfr; c++) {
         int s = SLOT_ROBOT + c;
-        R r[3] = {st.get(s, 0), st.get(s, 1), st.get(s, 2)};
-        R An = st.get(s, 3), Bt1 = st.get(s, 4), Bt2 = st.get(s, 5), D = st.get(s, 6);
+        R r[3], An, Bt1, Bt2, D;
+        if constexpr (PF) {
+          r[0] = nx_[0]; r[1] = nx_[1]; r[2] = nx_[2]; An = nx_[3]; Bt1 = nx_[4]; Bt2 = nx_[5]; D = nx_[6];
+          const int sn = SLOT_ROBOT + (c + 1 < N_ROBOT_SLOTS ? c + 1 : c);  // (the slot after the last contact holds stale but finite words)
+#pragma unroll
+          for (int w_ = 0; w_ < SLOT_WORDS; w_++) nx_[w_] = st.get(sn, w_);
+        } else {
+          r[0] = st.get(s, 0); r[1] = st.get(s, 1); r[2] = st.get(s, 2);
+          An = st.get(s, 3); Bt1 = st.get(s, 4); Bt2 = st.get(s, 5); D = st.get(s, 6);
+        }
         int sel = sel_robot(F.sels, c);
         R mu = sel == 0 ? P.cc[CC_TORSO_FLOOR].mu : F.muW;
         R wc[3], t[3];
