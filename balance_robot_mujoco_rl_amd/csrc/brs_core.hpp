@@ -79,6 +79,10 @@ __device__ __forceinline__ unsigned long long* brs_tim_slots() {  // 16 x u64 pe
 #ifndef BRS_FIXED_SCATTER
 #define BRS_FIXED_SCATTER 1
 #endif
+// fp32 velocity mirrors re-derived from the fp64 accumulators at the start of each substep (1) or carried across the solver (0)
+#ifndef BRS_LAZY_VEL32
+#define BRS_LAZY_VEL32 BRS_VEL64
+#endif
 // (Tried and not kept, round 3: the robot<->floor contacts in the same frame algebra as the patch -- they all share the world-aligned
 // frame, so they can accumulate one 8x8 matrix in (frame-coordinate twist, two wheel rates) and enter H by one congruence: 840
 // instead of ~1,400 instructions per trip on paper, but scalar and serially dependent where contact_into is packed and
@@ -295,6 +299,15 @@ template <typename R, bool BLK> struct EnvState {
 #if BRS_VEL64
   double vd[3], wd[3], wwd[2], bvd[3], bwd[3];  // the fp64 accumulators behind v, w, ww, bv, bw (those are their roundings)
 #endif
+  // the fp32 velocities the force path reads ARE the roundings of the fp64 accumulators: re-derived when a substep starts (and once
+  // after the loop) instead of being carried across the solver -- 14 registers less at the kernel's register peak, same numbers
+  BRS_HD void derive_vel32() {
+#if BRS_VEL64
+    for (int i = 0; i < 3; i++) { v[i] = (R)vd[i]; w[i] = (R)wd[i]; }
+    ww[0] = (R)wwd[0]; ww[1] = (R)wwd[1];
+    if constexpr (BLK) { for (int i = 0; i < 3; i++) { bv[i] = (R)bvd[i]; bw[i] = (R)bwd[i]; } }
+#endif
+  }
   BRS_HD void sync_vel64() {  // after code that wrote the fp32 velocities directly (reset, block throw)
 #if BRS_VEL64
     for (int i = 0; i < 3; i++) { vd[i] = (double)v[i]; wd[i] = (double)w[i]; }
@@ -731,16 +744,23 @@ template <typename R, bool BLK> struct Sim {
     make_frame(fw);
   }
   // ---- patch-frame algebra for the block<->torso patch (BRS_PATCH_FRAME).  All points of a patch share ONE contact frame
-  // (n, t1, t2).  In FRAME coordinates, with positions r' taken from the torso origin and c' = the block centre,
-  //     acceleration of the torso's material point at r':  aT' + wT' x r'          (aT' = Fm x[0:3], wT' = Fm x[3:6])
-  //     ... of the block's:                                 aB' + wB' x (r' - c')   (aB' = Ph x[8:11], wB' = Ph x[11:14])
-  // so every point's three frame rows are  K(r') tau,  K(r) = [I | -[r]x],  tau = (Vp, Wp) = (aB' - aT' + c' x wB', wB' - wT'): the
-  // RELATIVE twist at the torso origin, a linear map of the 12 dofs that does not depend on the point.  The patch's contribution
+  // (n, t1, t2).  In FRAME coordinates, with c' = the block centre seen from the torso origin and rho = r' - c' the position of a
+  // point seen from the BLOCK CENTRE,
+  //     acceleration of the block's material point:    aB' + wB' x rho                (aB' = Ph x[8:11], wB' = Ph x[11:14])
+  //     ... of the torso's:                             aT' + wT' x (c' + rho)         (aT' = Fm x[0:3], wT' = Fm x[3:6])
+  // so every point's three frame rows are  K(rho) tau,  K(r) = [I | -[r]x],  tau = (Vp, Wp) = (aB' - aT' + c' x wT', wB' - wT'): the
+  // RELATIVE twist at the block centre, a linear map of the 12 dofs that does not depend on the point.  The patch's contribution
   // to H is therefore  T^T (sum_c K_c^T W_c K_c) T  with a 6x6 matrix Z accumulated per point (~45 FMAs) and ONE congruence per
-  // pass; the rows at x, and the wrench of the patch, are 6-vectors mapped once.  Per point the passes read 7 LDS words
-  // (r', An, Bt1, Bt2, D).  Record of patch slot k (words): 0-2 r', 3 An, 4 Bt1, 5 Bt2, 6 D; words 7-9 of slots 0-2 hold the
-  // frame axes in the TORSO frame (Fm rows), of slots 3-5 in the BLOCK frame (Ph rows); contact-frame slot 0 holds c'.
-  struct Patch { R Fm[9], Ph[9], c[3]; };
+  // pass; the rows at x, and the wrench of the patch, are 6-vectors mapped once.
+  // WHY THE BLOCK CENTRE: the twist's reference point decides which body's angular acceleration meets the long lever |c'| ~ 0.15 m.
+  // Taken at the torso origin (first version of this algebra) it was the block's -- a 20-g cube that reaches 1e5 rad/s^2 in an
+  // impact -- and the block's point acceleration came out as the difference of two terms ten times its size: the one campaign
+  // env-step above 1e-4 of round 3 (Env03-v1, block quaternion 2.4e-4; 5.6e-5 with the per-point rank updates) was that
+  // cancellation.  At the block centre the long lever multiplies the torso's angular acceleration (<= 1e3 rad/s^2).
+  // Per point the passes read 7 LDS words (rho, An, Bt1, Bt2, D).  Record of patch slot k (words): 0-2 rho, 3 An, 4 Bt1, 5 Bt2,
+  // 6 D; words 7-9 of slots 0-2 hold the frame axes in the TORSO frame (Fm rows), of slots 3-5 in the BLOCK frame (Ph rows);
+  // contact-frame slot 0 holds c'.
+  struct Patch { R Fm[9], Ph[9], c[3], cT[3]; };  // cT: the block centre in the torso frame (patch_begin -> add_patch_point only)
   static_assert(!BRS_PATCH_FRAME || PATCH_MAX == 6, "the patch frame is parked in words 7-9 of patch slots 0-5");
   static BRS_HD void patch_load(const Store<R>& st, Patch& Q) {
 #pragma unroll
@@ -756,9 +776,9 @@ template <typename R, bool BLK> struct Sim {
     world_frame(F, nTf, fw);
 #pragma unroll
     for (int k = 0; k < 3; k++) { mulT_(F.RT, fw + 3 * k, Q.Fm + 3 * k); mulT_(F.RB, fw + 3 * k, Q.Ph + 3 * k); }
-    R dW[3] = {-F.dTB[0], -F.dTB[1], -F.dTB[2]}, cT[3];  // x_B - x_T (world) -> torso frame -> frame coordinates
-    mulT_(F.RT, dW, cT);
-    mul_(Q.Fm, cT, Q.c);
+    R dW[3] = {-F.dTB[0], -F.dTB[1], -F.dTB[2]};  // x_B - x_T (world) -> torso frame -> frame coordinates
+    mulT_(F.RT, dW, Q.cT);
+    mul_(Q.Fm, Q.cT, Q.c);
 #pragma unroll
     for (int k = 0; k < 3; k++)
 #pragma unroll
@@ -767,7 +787,7 @@ template <typename R, bool BLK> struct Sim {
     // velocities: S.v / S.bv are WORLD linear, S.w / S.bw BODY angular; frame coordinates of a world vector u: fw . u
     R vT[3], vB[3], wT[3], wB[3], t[3];
     mul_(fw, S.v, vT); mul_(fw, S.bv, vB); mul_(Q.Fm, S.w, wT); mul_(Q.Ph, S.bw, wB);
-    cross_(Q.c, wB, t);
+    cross_(Q.c, wT, t);
 #pragma unroll
     for (int k = 0; k < 3; k++) { V0[k] = vB[k] - vT[k] + t[k]; W0[k] = wB[k] - wT[k]; }
   }
@@ -775,7 +795,8 @@ template <typename R, bool BLK> struct Sim {
     if (F.nc >= PATCH_MAX) return;
     const ContactClass<R>& c = P.cc[CC_BLOCK_ROBOT];
     R r[3], t[3];
-    mul_(Q.Fm, rT, r);
+    const R dT[3] = {rT[0] - Q.cT[0], rT[1] - Q.cT[1], rT[2] - Q.cT[2]};
+    mul_(Q.Fm, dT, r);  // rho: the point seen from the block centre, frame coordinates
     cross_(W0, r, t);
     const R vn = V0[0] + t[0], vt1 = V0[1] + t[1], vt2 = V0[2] + t[2];
     const R imp = impedance_(c, dist);
@@ -1428,11 +1449,11 @@ template <typename R, bool BLK> struct Sim {
       }
     }
 
-    // relative acceleration twist of the patch at x, frame coordinates, taken at the torso origin (Sim::Patch)
+    // relative acceleration twist of the patch at x, frame coordinates, taken at the block centre (Sim::Patch)
     static BRS_HD void patch_twist(const Patch& Q, const R* x, R* Vp, R* Wp) {
       R aT[3], wT[3], aB[3], wB[3], t[3];
       mul_(Q.Fm, x, aT); mul_(Q.Fm, x + 3, wT); mul_(Q.Ph, x + 8, aB); mul_(Q.Ph, x + 11, wB);
-      cross_(Q.c, wB, t);
+      cross_(Q.c, wT, t);
 #pragma unroll
       for (int k = 0; k < 3; k++) { Vp[k] = aB[k] - aT[k] + t[k]; Wp[k] = wB[k] - wT[k]; }
     }
@@ -1458,14 +1479,14 @@ template <typename R, bool BLK> struct Sim {
           for (int k = 0; k < 3; k++) { Ft[k] += f[k]; Mt[k] += t[k]; }
         }
       }
-      if constexpr (FORCES) {  // wrench (at the torso origin) back to the dofs: -Fm^T on the torso, Ph^T on the block (moment about its centre)
+      if constexpr (FORCES) {  // wrench (at the block centre) back to the dofs: Ph^T on the block, -Fm^T on the torso (moment about ITS origin: + c' x F)
         R a[3], b[3], t[3];
-        mulT_(Q.Fm, Ft, a); mulT_(Q.Fm, Mt, b);
+        cross_(Q.c, Ft, t);
+        R mt[3] = {Mt[0] + t[0], Mt[1] + t[1], Mt[2] + t[2]};
+        mulT_(Q.Fm, Ft, a); mulT_(Q.Fm, mt, b);
 #pragma unroll
         for (int k = 0; k < 3; k++) { fcon[k] -= a[k]; fcon[3 + k] -= b[k]; }
-        cross_(Q.c, Ft, t);
-        R mb[3] = {Mt[0] - t[0], Mt[1] - t[1], Mt[2] - t[2]};
-        mulT_(Q.Ph, Ft, a); mulT_(Q.Ph, mb, b);
+        mulT_(Q.Ph, Ft, a); mulT_(Q.Ph, Mt, b);
 #pragma unroll
         for (int k = 0; k < 3; k++) { fcon[8 + k] += a[k]; fcon[11 + k] += b[k]; }
       }
@@ -1649,8 +1670,9 @@ template <typename R, bool BLK> struct Sim {
     }
 
     // the whole block<->torso patch into H / rhs: Z = sum_c K_c^T W_c K_c (6x6, twist space, frame coordinates) and
-    // z = sum_c K_c^T rho_c per point, then ONE congruence per dof block:  torso dofs J = -K diag(Fm), block dofs J = K S diag(Ph)
-    // with the shift S = [[I, [c']x], [0, I]] from the block centre to the torso origin
+    // z = sum_c K_c^T rho_c per point (K at rho = the point seen from the block centre), then ONE congruence per dof block:
+    // block dofs J = K diag(Ph), torso dofs J = -K S' diag(Fm) with the shift S' = [[I, -[c']x], [0, I]] from the torso origin to
+    // the block centre
     static BRS_HD void assemble_patch(const Params<R>& P, Store<R>& st, const Frame& F, Masks& M, bool first, uint32_t srcC,
                                       V2<R>* H, V2<R>* rhs2, const R* x) {
       Patch Q;
@@ -1692,21 +1714,22 @@ template <typename R, bool BLK> struct Sim {
       // 3x3 blocks as full matrices
       const R Zvv[9] = {Za, Zp, Zq, Zp, Zb, 0, Zq, 0, Zc};
       const R Zw[9] = {Zww[0], Zww[1], Zww[3], Zww[1], Zww[2], Zww[4], Zww[3], Zww[4], Zww[5]};
-      // shift to the block centre: Y10 = -[c]x Zvv + Zvw^T, Y11 = -[c]x Zvw + Zww, B11 = Y10 [c]x + Y11 (symmetric)
+      // the torso sees the twist through S' = [[I, -[c]x], [0, I]] (tau = -S' diag(Fm) x_T + diag(Ph) x_B):
+      // Y10 = [c]x Zvv + Zvw^T, Y11 = [c]x Zvw + Zww  (rows w of S'^T Z), B11 = -Y10 [c]x + Y11 = (S'^T Z S')_ww (symmetric)
       const R cx = Q.c[0], cy = Q.c[1], cz = Q.c[2];
       R Y10[9], Y11[9], B11[9];
 #pragma unroll
-      for (int j = 0; j < 3; j++) {  // column j of -[c]x X = -(c x X[:, j])
+      for (int j = 0; j < 3; j++) {  // column j of [c]x X = c x X[:, j]
         const R v0 = Zvv[j], v1 = Zvv[3 + j], v2 = Zvv[6 + j];
-        Y10[j] = -(cy * v2 - cz * v1) + Zvw[3 * j]; Y10[3 + j] = -(cz * v0 - cx * v2) + Zvw[3 * j + 1]; Y10[6 + j] = -(cx * v1 - cy * v0) + Zvw[3 * j + 2];
+        Y10[j] = (cy * v2 - cz * v1) + Zvw[3 * j]; Y10[3 + j] = (cz * v0 - cx * v2) + Zvw[3 * j + 1]; Y10[6 + j] = (cx * v1 - cy * v0) + Zvw[3 * j + 2];
         const R w0 = Zvw[j], w1 = Zvw[3 + j], w2 = Zvw[6 + j];
-        Y11[j] = -(cy * w2 - cz * w1) + Zw[j]; Y11[3 + j] = -(cz * w0 - cx * w2) + Zw[3 + j]; Y11[6 + j] = -(cx * w1 - cy * w0) + Zw[6 + j];
+        Y11[j] = (cy * w2 - cz * w1) + Zw[j]; Y11[3 + j] = (cz * w0 - cx * w2) + Zw[3 + j]; Y11[6 + j] = (cx * w1 - cy * w0) + Zw[6 + j];
       }
 #pragma unroll
-      for (int i = 0; i < 3; i++) {  // row i of X [c]x = (X[i,:] x c)... (X [c]x)[i][j] = sum_k X[i][k] [c]x[k][j] = (X[i,:] x c)_j with the sign below
+      for (int i = 0; i < 3; i++) {  // (X [c]x)[i][:] = X[i, :] x c
         const R y0 = Y10[3 * i], y1 = Y10[3 * i + 1], y2 = Y10[3 * i + 2];
         // [c]x = [[0, -cz, cy], [cz, 0, -cx], [-cy, cx, 0]]
-        B11[3 * i] = y1 * cz - y2 * cy + Y11[3 * i]; B11[3 * i + 1] = y2 * cx - y0 * cz + Y11[3 * i + 1]; B11[3 * i + 2] = y0 * cy - y1 * cx + Y11[3 * i + 2];
+        B11[3 * i] = -(y1 * cz - y2 * cy) + Y11[3 * i]; B11[3 * i + 1] = -(y2 * cx - y0 * cz) + Y11[3 * i + 1]; B11[3 * i + 2] = -(y0 * cy - y1 * cx) + Y11[3 * i + 2];
       }
       // congruences A^T X B into the lower triangle of H (rows ra.., columns ca..): out[i][j] = sum_{m,n} A[m][i] X[m][n] B[n][j]
       auto cong = [&](const R* A, const R* X, const R* B, R sgn, auto put) {
@@ -1726,25 +1749,30 @@ template <typename R, bool BLK> struct Sim {
 #pragma unroll
         for (int j = 0; j < 3; j++) ZvwT[3 * i + j] = Zvw[3 * j + i];
 #define BRS_HADD(ra, ca) [&](int i, int j, R v) { if ((ra) + i >= (ca) + j) hadd(H, (ra) + i, (ca) + j, v); }
+      R Y10T[9], Y11T[9];
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) { Y10T[3 * i + j] = Y10[3 * j + i]; Y11T[3 * i + j] = Y11[3 * j + i]; }
       cong(Q.Fm, Zvv, Q.Fm, (R)1, BRS_HADD(0, 0));     // torso lin-lin
-      cong(Q.Fm, ZvwT, Q.Fm, (R)1, BRS_HADD(3, 0));    // torso ang-lin  (Zwv = Zvw^T)
-      cong(Q.Fm, Zw, Q.Fm, (R)1, BRS_HADD(3, 3));      // torso ang-ang
+      cong(Q.Fm, Y10, Q.Fm, (R)1, BRS_HADD(3, 0));     // torso ang-lin
+      cong(Q.Fm, B11, Q.Fm, (R)1, BRS_HADD(3, 3));     // torso ang-ang
       cong(Q.Ph, Zvv, Q.Ph, (R)1, BRS_HADD(8, 8));     // block lin-lin
-      cong(Q.Ph, Y10, Q.Ph, (R)1, BRS_HADD(11, 8));    // block ang-lin
-      cong(Q.Ph, B11, Q.Ph, (R)1, BRS_HADD(11, 11));   // block ang-ang
-      cong(Q.Ph, Zvv, Q.Fm, (R)-1, BRS_HADD(8, 0));    // block lin x torso lin    (J_T = -K diag(Fm): minus)
-      cong(Q.Ph, Zvw, Q.Fm, (R)-1, BRS_HADD(8, 3));    // block lin x torso ang
-      cong(Q.Ph, Y10, Q.Fm, (R)-1, BRS_HADD(11, 0));   // block ang x torso lin
-      cong(Q.Ph, Y11, Q.Fm, (R)-1, BRS_HADD(11, 3));   // block ang x torso ang
+      cong(Q.Ph, ZvwT, Q.Ph, (R)1, BRS_HADD(11, 8));   // block ang-lin  (Zwv = Zvw^T)
+      cong(Q.Ph, Zw, Q.Ph, (R)1, BRS_HADD(11, 11));    // block ang-ang
+      cong(Q.Ph, Zvv, Q.Fm, (R)-1, BRS_HADD(8, 0));    // block lin x torso lin    (T_T = -S' diag(Fm): minus; columns of Z S')
+      cong(Q.Ph, Y10T, Q.Fm, (R)-1, BRS_HADD(8, 3));   // block lin x torso ang    ((Z S')_vw = Y10^T)
+      cong(Q.Ph, ZvwT, Q.Fm, (R)-1, BRS_HADD(11, 0));  // block ang x torso lin
+      cong(Q.Ph, Y11T, Q.Fm, (R)-1, BRS_HADD(11, 3));  // block ang x torso ang    ((Z S')_ww = Y11^T)
 #undef BRS_HADD
-      // rhs += J^T rho: torso -diag(Fm^T) z, block diag(Ph^T) S^T z with S^T z = (zv, zw - c x zv)
+      // rhs += J^T rho: torso -diag(Fm^T) S'^T z with S'^T z = (zv, zw + c x zv), block diag(Ph^T) z
       R a3[3], b3[3], t[3];
-      mulT_(Q.Fm, zv, a3); mulT_(Q.Fm, zw, b3);
+      cross_(Q.c, zv, t);
+      R zt[3] = {zw[0] + t[0], zw[1] + t[1], zw[2] + t[2]};
+      mulT_(Q.Fm, zv, a3); mulT_(Q.Fm, zt, b3);
 #pragma unroll
       for (int k = 0; k < 3; k++) { radd(rhs2, k, -a3[k]); radd(rhs2, 3 + k, -b3[k]); }
-      cross_(Q.c, zv, t);
-      R zb[3] = {zw[0] - t[0], zw[1] - t[1], zw[2] - t[2]};
-      mulT_(Q.Ph, zv, a3); mulT_(Q.Ph, zb, b3);
+      mulT_(Q.Ph, zv, a3); mulT_(Q.Ph, zw, b3);
 #pragma unroll
       for (int k = 0; k < 3; k++) { radd(rhs2, 8 + k, a3[k]); radd(rhs2, 11 + k, b3[k]); }
     }
@@ -1899,6 +1927,9 @@ template <typename R, bool BLK> struct Sim {
     R* f = C.f;
     BRS_MARK("begin_kin");
     BRS_TIC(0);
+#if BRS_LAZY_VEL32
+    S.derive_vel32();
+#endif
     // kinematics
     R qf[4] = {(R)S.q[0], (R)S.q[1], (R)S.q[2], (R)S.q[3]};
     quat2mat_(qf, F.RT);
@@ -2016,10 +2047,14 @@ template <typename R, bool BLK> struct Sim {
 #pragma unroll
     for (int i = 0; i < 3; i++) {
       S.vd[i] += P.h_d * (double)aw[i]; S.wd[i] += P.h_d * (double)acc[3 + i];
+#if !BRS_LAZY_VEL32
       S.v[i] = (R)S.vd[i]; S.w[i] = (R)S.wd[i];
+#endif
     }
     S.wwd[0] += P.h_d * (double)acc[6]; S.wwd[1] += P.h_d * (double)acc[7];
+#if !BRS_LAZY_VEL32
     S.ww[0] = (R)S.wwd[0]; S.ww[1] = (R)S.wwd[1];
+#endif
 #pragma unroll
     for (int i = 0; i < 3; i++) S.p[i] += P.h_d * S.vd[i];
     quat_advance(S.q, S.wd[0], S.wd[1], S.wd[2], P.h_d);
@@ -2044,7 +2079,9 @@ template <typename R, bool BLK> struct Sim {
 #pragma unroll
       for (int i = 0; i < 3; i++) {
         S.bvd[i] += P.h_d * (double)ab[i]; S.bwd[i] += P.h_d * (double)(fcon[11 + i] * P.inv_IB);
+#if !BRS_LAZY_VEL32
         S.bv[i] = (R)S.bvd[i]; S.bw[i] = (R)S.bwd[i];
+#endif
       }
 #pragma unroll
       for (int i = 0; i < 3; i++) S.bp[i] += P.h_d * S.bvd[i];
@@ -2060,9 +2097,9 @@ template <typename R, bool BLK> struct Sim {
     S.time += P.h_d;
     // first guess of the next substep's active set
     S.pnfr = F.nfr; S.pnfb = F.nfb; S.pnc = F.nc; S.psels = F.sels; S.pmR = C.M.nR; S.pmB = C.M.nB; S.pmC = C.M.nC;
-    for (int i_ = 0; i_ < 3; i_++) { BRS_PIN(S.v[i_]); BRS_PIN(S.w[i_]); BRS_PIN(S.p[i_]); }
+    for (int i_ = 0; i_ < 3; i_++) { BRS_PIN(S.vd[i_]); BRS_PIN(S.wd[i_]); BRS_PIN(S.p[i_]); }
     for (int i_ = 0; i_ < 4; i_++) BRS_PIN(S.q[i_]);
-    BRS_PIN(S.ww[0]); BRS_PIN(S.ww[1]);
+    BRS_PIN(S.wwd[0]); BRS_PIN(S.wwd[1]);
     BRS_TOC(7);
     BRS_STAT(int li = stats().last_iters[0]; stats().hist[li > 16 ? 16 : li]++; stats().trips += li > 1 ? li : 1; stats().substeps++;
              stats().trips_alt += (li == 2 && stats().first_single) ? 1 : (li > 1 ? li : 1));  // if a single-row flip were repaired inside the trip
@@ -2284,6 +2321,7 @@ template <typename R, bool BLK> struct Sim {
       }
       substep(P, st, S, ctrlL, ctrlR);
     }
+    S.derive_vel32();
     env_post(P, S, rng, rew, obs, terminal_obs, reward, terminated, truncated);
   }
 };

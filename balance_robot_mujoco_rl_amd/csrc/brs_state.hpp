@@ -242,6 +242,7 @@ BRS_HD void env_step_idx(const Params<R>& P, Store<R>& st, Stream<R>& rng, doubl
 #endif
     }
   }
+  S.derive_vel32();  // (BRS_LAZY_VEL32: the fp32 velocities env_post, the cost class and the stored state read)
 #if defined(__HIP_DEVICE_COMPILE__)
   asm volatile("" ::: "memory");  // re-read the pose from memory: do not keep it in registers across the loop
 #endif
@@ -294,6 +295,7 @@ BRS_HD void physics_mem(const Params<R>& P, Store<R>& st, double* d, FT* f, int*
       fresh = true;
     }
   }
+  S.derive_vel32();
   store_state<R, BLK, FT>(S, d, f, ii, N, i);
 }
 

@@ -31,6 +31,7 @@ template <typename R, bool BLK> struct Run {
     iters = 0;
     while (!C.conv) { SimT::sub_iter(P, st, S, C); iters++; }
     SimT::sub_end(P, S, C);
+    S.derive_vel32();  // (BRS_LAZY_VEL32: the fp32 mirrors are otherwise refreshed when the next substep starts)
   }
 };
 

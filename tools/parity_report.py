@@ -3,7 +3,7 @@
 finishes in minutes, HIP kernel vs oracle/ (fp64), teacher-forced per env step -- tools/parity_locate.py does the work
 (per-coordinate-group maxima, every env-step above 1e-4 dumped with its pre-step state and a substep-level replay).
 
-    python tools/parity_report.py [--quick] [--large] [--policy] [--ids] [--scratch: write under gpurun_out/parity/ instead of profiles/]
+    python tools/parity_report.py [--quick] [--large] [--policy] [--ids] [--only=name,name] [--scratch: write under gpurun_out/parity/ instead of profiles/]
         ->  profiles/r03_parity_config2.json, _config3.json, _config3_noreset.json [, _config3_large.json, _config3_policy.json, _ids_*.json]
 Oracle = oracle/brs_oracle.c (own fp64 restatement; MuJoCo is not installable here: physics parity vs MuJoCo UNPINNED)."""
 import os, subprocess, sys
@@ -21,6 +21,9 @@ if "--policy" in sys.argv:  # robots that stay up while blocks keep hitting them
 if "--ids" in sys.argv:     # the other registered ids, ~250 k env-steps each
     for e in ("Env01-v1", "Env01-v3", "Env02-v1", "Env03-v1"):
         runs.append((f"ids_{e}", ["--env", e, "--envs", "1024", "--steps", "250", "--actions", "random", "--auto-reset", "1"]))
+only = [a.split("=", 1)[1].split(",") for a in sys.argv if a.startswith("--only=")]  # e.g. --only=config3_large,config3_policy (one GPU call has 20 minutes)
+if only:
+    runs = [r for r in runs if r[0] in only[0]]
 for name, args in runs:
     out = os.path.join(outdir, f"r03_parity_{name}.json")
     print(f"== {name}", flush=True)
