@@ -16,7 +16,7 @@ TOL_QPOS = 1e-4
 # An env-step is UPRIGHT if the torso axis is within 60 degrees of vertical when the step starts (the env terminates at
 # 50 degrees of pitch, so with auto-reset every step it keeps is upright).  FALLEN robots exist only with auto-reset off.
 # Since round 3 (contact-existence and servo-clamp decisions from exact fp64 constants, fp64 velocity accumulators) the
-# north-star bound holds as a STRICT maximum in every group: 0 of 7.6 M campaign env-steps above 1e-4 (worst 8.6e-5, a block
+# north-star bound holds as a STRICT maximum in every group: 0 of 8.7 M campaign env-steps above 1e-4 (worst 8.6e-5, a block
 # quaternion under the balancing policy; robot coordinates 5.2e-5; fallen robots 7.2e-5).  The gates are that bound, with
 # zero exceptions, plus per-test caps at ~5-10x what the test's own sample measured (r03 GPU log), so that a regression of
 # one order of magnitude in the bulk fails even when no env-step crosses 1e-4:
@@ -200,7 +200,10 @@ def test_constructed_block_robot_contact_states_on_the_hip_path():
     err, vo = _constructed("Env03-v2", qpos, qvel, np.zeros((len(qpos), 2)), 5)
     assert (np.abs(vo[:, :6]).max(axis=1) > 1e-6).sum() > len(qpos) // 3, "a coupled contact acted on the robot"
     print(f"block<->robot constructed states on HIP: rel. velocity error q98 {np.quantile(err, 0.98):.3g}, max {err.max():.3g}")
-    assert np.quantile(err, 0.98) < 3e-6 and err.max() < 1e-5, (np.quantile(err, 0.98), err.max())   # measured 3.1e-7 / 7.0e-7
+    # measured 2.8e-7 / 3.1e-7 (deterministic arithmetic).  The cap on the maximum sits BELOW the 7.0e-7 the first version of the
+    # patch-frame algebra reached (relative twist taken at the torso origin: the block's point acceleration as a difference of two
+    # large terms) -- the form that put one campaign env-step at 2.4e-4
+    assert np.quantile(err, 0.98) < 5e-7 and err.max() < 5e-7, (np.quantile(err, 0.98), err.max())
 
 
 def test_constructed_edge_edge_states_on_the_hip_path():
