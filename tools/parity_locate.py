@@ -69,21 +69,22 @@ def main():
     ap.add_argument("--actions", choices=["random", "zero", "policy"], default="random",
                     help="policy = the reference's MuJoCo-trained balance policy (tests/quant_policy.py) acting on the teacher's observations")
     ap.add_argument("--max-dump", type=int, default=40)
+    ap.add_argument("--seed", type=int, default=0, help="seed of both simulators' Philox streams and of the action generator (0 = the campaign of profiles/r03_parity_*.json)")
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r03_parity_outliers.json"))
     a = ap.parse_args()
     n, thr = a.envs, min(os.cpu_count() or 1, 64)
     ar = bool(a.auto_reset)
     if a.teacher == "oracle":
         from oracle import oracle as O
-        T = O.Oracle(a.env, n, seed=0, auto_reset=ar, noise=False, threads=thr)
+        T = O.Oracle(a.env, n, seed=a.seed, auto_reset=ar, noise=False, threads=thr)
     else:
-        T = HostSim(a.env, n, seed=0, auto_reset=ar, noise=False, double=True, threads=thr)
+        T = HostSim(a.env, n, seed=a.seed, auto_reset=ar, noise=False, double=True, threads=thr)
     if a.student == "gpu":
         import torch
         from balance_robot_mujoco_rl_amd import BatchedSim
-        S = BatchedSim(a.env, n, device=0, seed=0, auto_reset=ar, obs_noise=False)
+        S = BatchedSim(a.env, n, device=0, seed=a.seed, auto_reset=ar, obs_noise=False)
     else:
-        S = HostSim(a.env, n, seed=0, auto_reset=ar, noise=False, double=False, threads=thr)
+        S = HostSim(a.env, n, seed=a.seed, auto_reset=ar, noise=False, double=False, threads=thr)
     obs_t = T.reset(); S.reset()
     pol = None
     if a.actions == "policy":
@@ -92,7 +93,7 @@ def main():
         from quant_policy import QuantMovePolicy
         _qp = QuantMovePolicy()
         pol = lambda o: _qp.act(_torch.from_numpy(np.ascontiguousarray(o, dtype=np.float32)), "mean").numpy()
-    rng = np.random.default_rng(1234)
+    rng = np.random.default_rng(1234 + a.seed)
     outl, nsteps, over, excl, worst = [], 0, 0, 0, 0.0
     upright_over, upright_n = 0, 0
     # per coordinate group x {upright, fallen}: max error and number of env-steps above tol
@@ -141,13 +142,14 @@ def main():
             ctrl = qvel[i, 6:8] + act[i].astype(np.float64) * 4.0
             rec = dict(env=int(i), step=int(t), max_dqpos=float(e[i]), per_group=group_err(qs[i] - qt[i]),
                        upright=bool(upright[i]), tilt_deg=float(np.degrees(np.arccos(np.clip(1 - 2 * (qpos[i, 4] ** 2 + qpos[i, 5] ** 2), -1, 1)))),
-                       pre=dict(qpos=qpos[i].tolist(), qvel=qvel[i].tolist(), warm=warm[i].tolist(), time=float(tm[i]), ctrl=ctrl.tolist()),
+                       pre=dict(qpos=qpos[i].tolist(), qvel=qvel[i].tolist(), warm=warm[i].tolist(), time=float(tm[i]), ctrl=ctrl.tolist(),
+                                aux=aux[i].tolist(), xquat=xq[i].tolist(), xpos=xp[i].tolist(), action=act[i].tolist()),  # (aux / accessor pose / action: what a replay through brs_step needs)
                        contacts_pre=contacts_of(a.env, qpos[i], qvel[i], tm[i]))
             rec["replay_host_double_vs_float"] = replay(a.env, qpos[i], qvel[i], warm[i], float(tm[i]), aux[i], ctrl, a.tol)
             outl.append(rec)
         if t % 50 == 0:
             print(f"step {t}: worst {worst:.3g}, over {over}/{nsteps} ({time.time() - t0:.0f} s)", flush=True)
-    rep = dict(env=a.env, envs=n, steps=a.steps, teacher=a.teacher, student=a.student, auto_reset=ar, tol=a.tol, actions=a.actions,
+    rep = dict(env=a.env, envs=n, steps=a.steps, seed=a.seed, teacher=a.teacher, student=a.student, auto_reset=ar, tol=a.tol, actions=a.actions,
                env_steps=nsteps, excluded=excl, over=over, worst=worst, upright_env_steps=upright_n, upright_over=upright_over,
                per_group={k: dict(max=v[0], over_tol=v[1]) for k, v in gstat.items()},
                log10_error_histogram={f"1e{k - 11}": int(v) for k, v in enumerate(hist)}, outliers=outl)
