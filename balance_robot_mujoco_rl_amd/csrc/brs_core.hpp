@@ -808,6 +808,59 @@ template <typename R, bool BLK> struct Sim {
     st.setc(k, 6, imp * rcp_((1 - imp) * c.cD));
     F.nc++;
   }
+  // The 15-axis separation test once more, entirely from the fp64 poses (same formulas and tie rules as the fp32 code in
+  // collide_coupled and as oracle/brs_oracle.c: bo_box_box_points).  Called only when the fp32 test sits within rounding of one
+  // of its DISCRETE outcomes -- two face axes (or two edge axes) with the same separation, or the edge axis at its hysteresis
+  // threshold against the face axis: which axis wins decides between different contact sets (one edge-edge point or a clipped
+  // face patch; one reference face or its neighbour), and a kernel that takes that decision on fp32 roundings leaves the fp64
+  // oracle by the whole difference of the two sets.  Round 3's second campaign seed found this: 3 env-steps of 3 M with a block
+  // quaternion at 2.0-2.7e-4, each a jump at one substep with the contact set of the other branch.  ~330 fp64 operations, rare.
+  struct Sat64 { double bestF, bestE; int axF, axE; bool sep; };
+  static BRS_HD Sat64 sat15_f64(const Params<R>& P, const ES& S) {
+    double qT[4] = {S.q[0], S.q[1], S.q[2], S.q[3]}, qB[4] = {S.bq[0], S.bq[1], S.bq[2], S.bq[3]}, T64[9], B64[9], RTB[9], Q[9], cg[3];
+    quat2mat_(qT, T64); quat2mat_(qB, B64);
+    const double d64[3] = {S.bp[0] - S.p[0], S.bp[1] - S.p[1], S.bp[2] - S.p[2]};
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      cg[i] = T64[i] * d64[0] + T64[3 + i] * d64[1] + T64[6 + i] * d64[2] - (i == 2 ? P.torso_cz_d : 0.0);
+#pragma unroll
+      for (int j = 0; j < 3; j++) { RTB[3 * i + j] = T64[i] * B64[j] + T64[3 + i] * B64[3 + j] + T64[6 + i] * B64[6 + j]; Q[3 * i + j] = abs_(RTB[3 * i + j]); }
+    }
+    const double sT[3] = {P.torso_s_d[0], P.torso_s_d[1], P.torso_s_d[2]}, s = P.block_s_d, mg = P.margin_d[CC_BLOCK_ROBOT];
+    Sat64 o;
+    o.bestF = -1e300; o.bestE = -1e300; o.axF = 0; o.axE = -1; o.sep = false;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const double sp = abs_(cg[k]) - sT[k] - s * (Q[3 * k] + Q[3 * k + 1] + Q[3 * k + 2]);
+      o.sep = o.sep | (sp > mg);
+      const bool better = sp > o.bestF;
+      o.bestF = better ? sp : o.bestF; o.axF = better ? k : o.axF;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const double dB = cg[0] * RTB[j] + cg[1] * RTB[3 + j] + cg[2] * RTB[6 + j];
+      const double sp = abs_(dB) - s - (sT[0] * Q[j] + sT[1] * Q[3 + j] + sT[2] * Q[6 + j]);
+      o.sep = o.sep | (sp > mg);
+      const bool better = sp > o.bestF;
+      o.bestF = better ? sp : o.bestF; o.axF = better ? 3 + j : o.axF;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+        const double len2 = 1.0 - RTB[3 * i + j] * RTB[3 * i + j];
+        const double cl = cg[i2] * RTB[3 * i1 + j] - cg[i1] * RTB[3 * i2 + j];
+        const double rT = sT[i1] * Q[3 * i2 + j] + sT[i2] * Q[3 * i1 + j], rB = s * (Q[3 * i + j1] + Q[3 * i + j2]);
+        const bool ok = len2 >= 1e-6;
+        const double sp = (abs_(cl) - rT - rB) * rsqrt64_(ok ? len2 : 1.0);
+        o.sep = o.sep | (ok & (sp > mg));
+        const bool better = ok & (sp > o.bestE);
+        o.bestE = better ? sp : o.bestE; o.axE = better ? 3 * i + j : o.axE;
+      }
+    }
+    return o;
+  }
   // everything in the TORSO frame: block centre cB, block axes as columns of RTB = RT^T RB
   static BRS_HD void collide_coupled(const Params<R>& P, Store<R>& st, Frame& F, const ES& S) {
     const ContactClass<R>& c = P.cc[CC_BLOCK_ROBOT];
@@ -840,7 +893,7 @@ template <typename R, bool BLK> struct Sim {
       R Q[9];
 #pragma unroll
       for (int i = 0; i < 9; i++) Q[i] = abs_(RTB[i]);
-      R bestF = (R)-1e30, bestE = (R)-1e30;
+      R bestF = (R)-1e30, bestE = (R)-1e30, bestF2 = (R)-1e30, bestE2 = (R)-1e30;  // (best and runner-up separations)
       double bestE64 = 0;
       int axF = 0, axE = -1;
       bool sep = false;
@@ -856,6 +909,7 @@ template <typename R, bool BLK> struct Sim {
         R sp = abs_(cg[k]) - sT[k] - s * (Q[3 * k] + Q[3 * k + 1] + Q[3 * k + 2]);
         sep = sep | (sp > sat_margin);
         const bool better = sp > bestF;
+        bestF2 = better ? bestF : max_(bestF2, sp);
         bestF = better ? sp : bestF; axF = better ? k : axF;
       }
 #pragma unroll
@@ -864,6 +918,7 @@ template <typename R, bool BLK> struct Sim {
         R sp = abs_(dB) - s - (sT[0] * Q[j] + sT[1] * Q[3 + j] + sT[2] * Q[6 + j]);
         sep = sep | (sp > sat_margin);
         const bool better = sp > bestF;
+        bestF2 = better ? bestF : max_(bestF2, sp);
         bestF = better ? sp : bestF; axF = better ? 3 + j : axF;
       }
 #pragma unroll
@@ -871,19 +926,38 @@ template <typename R, bool BLK> struct Sim {
 #pragma unroll
         for (int j = 0; j < 3; j++) {
           const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
-          R len2 = (R)1 - RTB[3 * i + j] * RTB[3 * i + j];
+          // |e_i x b_j|^2 as the sum of squares of the cross product's two components, NOT as 1 - r_ij^2: for nearly parallel edges
+          // (a block lying flat on the torso: len2 ~ 1e-5) the fp32 difference carries 1e-7 of absolute error, i.e. 1 % of len2 -- the
+          // separation of such an axis came out wrong by 1-2 mm and beat the face axis (round 3, seed-1 campaign: a 4-point patch
+          // replaced by one edge-edge point for a substep)
+          R len2 = RTB[3 * i1 + j] * RTB[3 * i1 + j] + RTB[3 * i2 + j] * RTB[3 * i2 + j];
           R cl = cg[i2] * RTB[3 * i1 + j] - cg[i1] * RTB[3 * i2 + j];
           R rT = sT[i1] * Q[3 * i2 + j] + sT[i2] * Q[3 * i1 + j], rB = s * (Q[3 * i + j1] + Q[3 * i + j2]);
           R sp = (abs_(cl) - rT - rB) * rsqrt_(max_(len2, (R)1e-12));
           const bool ok = len2 >= (R)1e-6;
           sep = sep | (ok & (sp > sat_margin));
           const bool better = ok & (sp > bestE);
+          bestE2 = better ? bestE : (ok ? max_(bestE2, sp) : bestE2);
           bestE = better ? sp : bestE; axE = better ? 3 * i + j : axE;
         }
       }
+      bool use_edge = (axE >= 0) & (bestE > bestF + (R)0.05 * abs_(bestF) + (R)1e-5);
+#if !defined(BRS_PATCH_DIST32)
+      if (sizeof(R) == 4 && !sep) {
+        // a DISCRETE outcome within rounding of a tie (fp32 separations carry ~1e-8 m; band 2e-6 m): two face axes level, the edge
+        // axis at its threshold against the face axis, or -- where the edge axis may win -- two edge axes level.  Then all
+        // fifteen separations are taken from the fp64 poses and the choices from those (sat15_f64)
+        const R band = (R)2e-6, thr = bestF + (R)0.05 * abs_(bestF) + (R)1e-5;
+        const bool tie = (bestF - bestF2 < band) | ((axE >= 0) & ((abs_(bestE - thr) < band) | ((bestE > thr - band) & (bestE - bestE2 < band))));
+        if (tie) {
+          const Sat64 d = sat15_f64(P, S);
+          sep = d.sep; axF = d.axF; axE = d.axE; bestE = (R)d.bestE;
+          use_edge = (d.axE >= 0) & (d.bestE > d.bestF + 0.05 * abs_(d.bestF) + 1e-5);
+        }
+      }
+#endif
       if (!sep) {
         BRS_MARK("cc_branch");
-        const bool use_edge = (axE >= 0) & (bestE > bestF + (R)0.05 * abs_(bestF) + (R)1e-5);
         if (use_edge) {
           const int i = axE / 3, j = axE - 3 * i;
           const int i1 = i == 2 ? 0 : i + 1, i2 = i == 0 ? 2 : i - 1;
@@ -915,7 +989,8 @@ template <typename R, bool BLK> struct Sim {
           if (edge_in) {
             R bj[3] = {pick3(j, RTB[0], RTB[1], RTB[2]), pick3(j, RTB[3], RTB[4], RTB[5]), pick3(j, RTB[6], RTB[7], RTB[8])};
             const R bji = pick3(i, bj), bji1 = pick3(i1, bj), bji2 = pick3(i2, bj);
-            R il = rsqrt_((R)1 - bji * bji);
+            const R lenE2 = bji1 * bji1 + bji2 * bji2;  // = 1 - bji^2 without the cancellation
+            R il = rsqrt_(lenE2);
             // L = e_i x b_j : L[i1] = -b_j[i2], L[i2] = b_j[i1]
             R Lv1 = -bji2 * il, Lv2 = bji1 * il;
             R L[3];
@@ -935,7 +1010,7 @@ template <typename R, bool BLK> struct Sim {
               for (int q = 0; q < 3; q++) pB[q] += sg * bm[q];
             }
             R w[3] = {pA[0] - pB[0], pA[1] - pB[1], pA[2] - pB[2]};
-            R dA = pick3(i, w), dBv = dot_(w, bj), iden = rcp_((R)1 - bji * bji);
+            R dA = pick3(i, w), dBv = dot_(w, bj), iden = rcp_(lenE2);
             R al = (bji * dBv - dA) * iden, be = (dBv - bji * dA) * iden;
             const R sTi = pick3(i, sT);
             al = max_(-sTi, min_(sTi, al)); be = max_(-s, min_(s, be));
@@ -965,7 +1040,8 @@ template <typename R, bool BLK> struct Sim {
           // the fp64 poses: every candidate's signed distance g is affine in these three numbers, and g < margin decides
           // whether a patch point exists in this substep -- in fp32 its rounding (~1e-8 m) put points of the patch one
           // substep apart from the fp64 oracle (the block-quaternion outliers of DESIGN.md 2.1).  ~120 fp64 operations.
-          double Cc2, H12, H22;
+          double Cc2, H12, H22, fsg = 1.0, fsj = 1.0;
+          int fsel = 0;
           {
             double qT[4] = {S.q[0], S.q[1], S.q[2], S.q[3]}, qB[4] = {S.bq[0], S.bq[1], S.bq[2], S.bq[3]}, T64[9], B64[9];
             quat2mat_(qT, T64); quat2mat_(qB, B64);
@@ -978,16 +1054,20 @@ template <typename R, bool BLK> struct Sim {
               const double rk[3] = {ck[0] * B64[0] + ck[1] * B64[3] + ck[2] * B64[6], ck[0] * B64[1] + ck[1] * B64[4] + ck[2] * B64[7],
                                     ck[0] * B64[2] + ck[1] * B64[5] + ck[2] * B64[8]};  // row k of RTB
               const double cgk = ck[0] * d64[0] + ck[1] * d64[1] + ck[2] * d64[2] - (k == 2 ? cz : 0.0);
-              const double sg = pick3(k, cg) >= 0 ? 1.0 : -1.0;
-              int js = 0;  // (same discrete choices as the fp32 code below, made on the fp32 values)
+              // the DISCRETE choices of the face case -- which side of the reference face, which face of the other box is
+              // incident and its sign -- are taken HERE, on the fp64 values, and handed to the fp32 code below (fsel, fsg, fsj):
+              // a block turned 45 degrees about the normal has two faces equally anti-parallel to it, and the two choices are
+              // different patches
+              const double sg = cgk >= 0 ? 1.0 : -1.0;
+              int js = 0;
+              if (abs_(rk[1]) > abs_(rk[0])) js = 1;
+              if (abs_(rk[2]) > abs_(pick3(js, rk))) js = 2;
               {
-                const R r0 = pick3(k, RTB[0], RTB[3], RTB[6]), r1 = pick3(k, RTB[1], RTB[4], RTB[7]), r2 = pick3(k, RTB[2], RTB[5], RTB[8]);
-                if (abs_(r1) > abs_(r0)) js = 1;
-                if (abs_(r2) > abs_(pick3(js, r0, r1, r2))) js = 2;
-                const double sj = -sg * (pick3(js, r0, r1, r2) >= 0 ? 1.0 : -1.0);
+                const double sj = -sg * (pick3(js, rk) >= 0 ? 1.0 : -1.0);
                 const int a1 = js == 2 ? 0 : js + 1, a2 = js == 0 ? 2 : js - 1;
                 Cc2 = sg * (cgk + sj * sd * pick3(js, rk)) - pick3(k, sTd);
                 H12 = sg * sd * pick3(a1, rk); H22 = sg * sd * pick3(a2, rk);
+                fsel = js; fsg = sg; fsj = sj;
               }
             } else {
               const int j = axF - 3;
@@ -995,12 +1075,12 @@ template <typename R, bool BLK> struct Sim {
               const double bj64[3] = {T64[0] * cj[0] + T64[3] * cj[1] + T64[6] * cj[2], T64[1] * cj[0] + T64[4] * cj[1] + T64[7] * cj[2],
                                       T64[2] * cj[0] + T64[5] * cj[1] + T64[8] * cj[2]};  // the same axis in the torso frame
               const double dotbc = cj[0] * d64[0] + cj[1] * d64[1] + cj[2] * d64[2] - bj64[2] * cz;  // bj . cg
-              const R bjf[3] = {pick3(j, RTB[0], RTB[1], RTB[2]), pick3(j, RTB[3], RTB[4], RTB[5]), pick3(j, RTB[6], RTB[7], RTB[8])};
-              const double sgB = dot_(cg, bjf) >= 0 ? 1.0 : -1.0;
+              const double sgB = dotbc >= 0 ? 1.0 : -1.0;  // (discrete choices on the fp64 values, as above)
               int ks = 0;
-              if (abs_(bjf[1]) > abs_(bjf[0])) ks = 1;
-              if (abs_(bjf[2]) > abs_(pick3(ks, bjf))) ks = 2;
-              const double sk = sgB * (pick3(ks, bjf) >= 0 ? 1.0 : -1.0);
+              if (abs_(bj64[1]) > abs_(bj64[0])) ks = 1;
+              if (abs_(bj64[2]) > abs_(pick3(ks, bj64))) ks = 2;
+              const double sk = sgB * (pick3(ks, bj64) >= 0 ? 1.0 : -1.0);
+              fsel = ks; fsg = sgB; fsj = sk;
               const int a1 = ks == 2 ? 0 : ks + 1, a2 = ks == 0 ? 2 : ks - 1;
               Cc2 = -sgB * (sk * pick3(ks, sTd) * pick3(ks, bj64) - dotbc) - sd;
               H12 = -sgB * pick3(a1, sTd) * pick3(a1, bj64); H22 = -sgB * pick3(a2, sTd) * pick3(a2, bj64);
@@ -1009,12 +1089,17 @@ template <typename R, bool BLK> struct Sim {
 #endif
           if (axF < 3) {
             const int k = axF, j1 = k == 2 ? 0 : k + 1, j2 = k == 0 ? 2 : k - 1;
+#if defined(BRS_PATCH_DIST32)
             const R sg = pick3(k, cg) >= 0 ? (R)1 : (R)-1;
             R rk[3] = {pick3(k, RTB[0], RTB[3], RTB[6]), pick3(k, RTB[1], RTB[4], RTB[7]), pick3(k, RTB[2], RTB[5], RTB[8])};  // row k
             int js = 0;
             if (abs_(rk[1]) > abs_(rk[0])) js = 1;
             if (abs_(rk[2]) > abs_(pick3(js, rk))) js = 2;
             const R sj = -sg * (pick3(js, rk) >= 0 ? (R)1 : (R)-1);
+#else
+            const R sg = (R)fsg, sj = (R)fsj;  // side, incident face and its sign: decided above on the fp64 values
+            const int js = fsel;
+#endif
             const int a1 = js == 2 ? 0 : js + 1, a2 = js == 0 ? 2 : js - 1;
             // block axes (torso frame) js, a1, a2 = columns of RTB
             R bs[3] = {pick3(js, RTB[0], RTB[1], RTB[2]), pick3(js, RTB[3], RTB[4], RTB[5]), pick3(js, RTB[6], RTB[7], RTB[8])};
@@ -1036,11 +1121,16 @@ template <typename R, bool BLK> struct Sim {
             R bj[3] = {pick3(j, RTB[0], RTB[1], RTB[2]), pick3(j, RTB[3], RTB[4], RTB[5]), pick3(j, RTB[6], RTB[7], RTB[8])};
             R bi1[3] = {pick3(i1, RTB[0], RTB[1], RTB[2]), pick3(i1, RTB[3], RTB[4], RTB[5]), pick3(i1, RTB[6], RTB[7], RTB[8])};
             R bi2[3] = {pick3(i2, RTB[0], RTB[1], RTB[2]), pick3(i2, RTB[3], RTB[4], RTB[5]), pick3(i2, RTB[6], RTB[7], RTB[8])};
+#if defined(BRS_PATCH_DIST32)
             const R sgB = dot_(cg, bj) >= 0 ? (R)1 : (R)-1;
             int ks = 0;
             if (abs_(bj[1]) > abs_(bj[0])) ks = 1;
             if (abs_(bj[2]) > abs_(pick3(ks, bj))) ks = 2;
             const R sk = sgB * (pick3(ks, bj) >= 0 ? (R)1 : (R)-1);
+#else
+            const R sgB = (R)fsg, sk = (R)fsj;
+            const int ks = fsel;
+#endif
             const int a1 = ks == 2 ? 0 : ks + 1, a2 = ks == 0 ? 2 : ks - 1;
             const R sTs = pick3(ks, sT), sT1 = pick3(a1, sT), sT2 = pick3(a2, sT);
             // incident torso face: centre sk sT[ks] e_ks, half edges sT[a1] e_a1, sT[a2] e_a2; into the block frame: R^T (x - cg)

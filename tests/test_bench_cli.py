@@ -45,3 +45,29 @@ def test_spawn_builds_a_torch_distributed_run_child_with_the_same_arguments(monk
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-6:] == ["--gpus", "2", "--steps", "7", "--streams", "2"] and os.path.abspath(cmd[-7]) == BENCH
     assert seen["env"].get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_spawned_two_ranks_on_one_gpu_report_the_whole_job():
+    """the whole `--gpus 2` path with the real kernels: bench.py spawns `torch.distributed.run` as a child, both ranks step their own
+    shard (global env indices 0..n-1 / n..2n-1), barrier + synchronize around the timed loop, MAX over ranks, rank 0 prints ONE line
+    whose value is the aggregate.  One GPU is all a test box has, so both ranks share device 0 and the timing reduction goes over
+    gloo (BRS_BENCH_ONE_DEVICE / BRS_BENCH_BACKEND: rehearsal switches; the driver's 8-GPU run uses RCCL and one device per rank)."""
+    import json
+    env = dict(os.environ, BRS_BENCH_ONE_DEVICE="1", BRS_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    args = ["--gpus", "2", "--env", "Env03-v2", "--envs", "4096", "--steps", "6", "--warmup", "2", "--no-cpu-baseline"]
+    p = subprocess.run([sys.executable, BENCH] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["envs_per_gpu"] == 4096 and "8192 total" in d["config"]["workload"]
+    # aggregate over both ranks: 2 x 4096 envs per step of the slower rank
+    assert abs(d["value"] - 2 * 4096 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert d["value"] > 1e5
