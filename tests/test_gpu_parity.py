@@ -226,6 +226,27 @@ def test_constructed_floor_contact_states_on_the_hip_path():
     assert np.quantile(err, 0.98) < 5e-7 and err.max() < 1e-6, (np.quantile(err, 0.98), err.max())   # measured 2.8e-8 / 3.8e-8
 
 
+def test_round3_outlier_states_stay_fixed_on_the_hip_path():
+    """tests/golden/round3_outlier_states.json: the env-steps round 3's campaigns found above 1e-4 (block quaternion 2.4-2.7e-4),
+    replayed on the HIP path (250 fused substeps from the dumped pre-step state) against the oracle"""
+    import json
+    from balance_robot_mujoco_rl_amd import BatchedSim
+    from oracle import oracle as O
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "round3_outlier_states.json")))
+    for st in fx["states"]:
+        pre = st["pre"]
+        qpos, qvel, warm = (np.array(pre[k], dtype=np.float64)[None] for k in ("qpos", "qvel", "warm"))
+        tm, ctrl = np.array([pre["time"]]), np.array(pre["ctrl"], dtype=np.float64)
+        sim = BatchedSim(st["env"], 1, device=0, seed=0, auto_reset=False, obs_noise=False)
+        orc = O.Oracle(st["env"], 1, seed=0, auto_reset=False, noise=False)
+        sim.set_state(qpos, qvel, warm, tm); orc.set_state(qpos, qvel, warm, tm)
+        sim.physics(ctrl.astype(np.float32)[None], 250); orc.physics(ctrl[None], 250)
+        d = float(np.abs(sim.get_state()[0][0] - orc.get_state()[0][0]).max())
+        print(f"{st['env']}: {st['why']}: now {d:.3g}")
+        assert d < 1e-5, (st["why"], d)   # measured 1e-9 - 2e-8
+        sim.close(); orc.close()
+
+
 def test_config4_per_node_total_on_one_gpu():
     """BASELINE config 4's per-node total (524,288 Env03-v2 envs) in ONE launch on one GPU: size-independent invariants,
     and bit-identity of a 65,536-env shard with a standalone handle over the same global indices (what the 8-GPU run

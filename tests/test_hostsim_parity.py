@@ -148,3 +148,23 @@ def test_float_build_stays_on_the_double_build_over_full_env_steps(env_id, n, st
     assert kept > 0.9 * n * steps
     assert worst < 5e-5, worst
     assert over5 <= 3, (over5, kept)
+
+
+def test_round3_outlier_states_stay_fixed():
+    """the env-steps round 3's parity campaigns found above 1e-4 (block quaternion 2.4-2.7e-4) and their causes -- the patch twist
+    taken at the torso origin, an edge-axis length lost to cancellation, a discrete axis choice on fp32 roundings -- as regression
+    fixtures: the kernel source in FLOAT stays on its DOUBLE instantiation over the 250 substeps of that step"""
+    import json, os
+    from tests.hostsim.hostsim import HostSim
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "round3_outlier_states.json")))
+    for st in fx["states"]:
+        pre = st["pre"]
+        qpos, qvel, warm = (np.array(pre[k])[None] for k in ("qpos", "qvel", "warm"))
+        res = []
+        for dbl in (True, False):
+            h = HostSim(st["env"], 1, noise=False, double=dbl)
+            h.set_state(qpos, qvel, warm, np.array([pre["time"]]))
+            h.physics(np.array(pre["ctrl"])[None], 250)
+            res.append(h.get_state()[0][0])
+        d = np.abs(res[0] - res[1]).max()
+        assert d < 2e-6, (st["why"], d)   # measured <= 3e-8; the three were 2.4e-4 - 2.7e-4 (the first one on the GPU only)
