@@ -4,7 +4,8 @@ in DESIGN.md 2.1 and write profiles/r03_parity_report.json; exits non-zero if an
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rep, unexplained = {}, 0
-for cfg in ("config2", "config3", "config3_noreset", "config3_large", "config3_policy", "ids_Env01-v1", "ids_Env01-v3", "ids_Env02-v1", "ids_Env03-v1"):
+for cfg in ("config2", "config3", "config3_noreset", "config3_large", "config3_policy", "ids_Env01-v1", "ids_Env01-v3", "ids_Env02-v1", "ids_Env03-v1") + \
+        tuple(f"config3_{w}_seed{k}" for k in range(1, 10) for w in ("large", "policy")):  # (other seeds: tools/parity_more.sh)
     path = os.path.join(ROOT, "profiles", f"r03_parity_{cfg}.json")
     if not os.path.exists(path):
         continue
