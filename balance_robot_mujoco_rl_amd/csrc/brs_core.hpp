@@ -861,6 +861,77 @@ template <typename R, bool BLK> struct Sim {
     }
     return o;
   }
+  // The wheel<->block candidates' distances once more from the fp64 poses: the deepest of (a) the 8 block vertices and (b) the
+  // points of the 12 block edges nearest the cylinder axis, each against the capped cylinder, (c) two cylinder surface points
+  // against the box -- same candidates and guards as collide_coupled (ii) and oracle/brs_oracle.c: bo_box_cyl_point.  Only the
+  // DISTANCE is returned: it decides whether the wheel<->block contact exists in this substep, and that decision was the one
+  // contact-existence test still taken in fp32 (seed 5 of round 3's campaign: a block arriving at a wheel had its contact one
+  // substep early, 2.1e-4 on its quaternion).  Called only when the fp32 distance is within 2 um of the margin.
+  static BRS_HD double wheel_block_dist_f64(const Params<R>& P, const ES& S, int wsel) {
+    double qT[4] = {S.q[0], S.q[1], S.q[2], S.q[3]}, qB[4] = {S.bq[0], S.bq[1], S.bq[2], S.bq[3]}, T64[9], B64[9], RTB[9], d[3];
+    quat2mat_(qT, T64); quat2mat_(qB, B64);
+    const double dw[3] = {S.bp[0] - S.p[0], S.bp[1] - S.p[1], S.bp[2] - S.p[2]};
+    const double wp[3] = {wsel == 1 ? -P.wheel_px_d : P.wheel_px_d, 0.0, P.wheel_pz_d};
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      d[i] = T64[i] * dw[0] + T64[3 + i] * dw[1] + T64[6 + i] * dw[2] - wp[i];
+#pragma unroll
+      for (int j = 0; j < 3; j++) RTB[3 * i + j] = T64[i] * B64[j] + T64[3 + i] * B64[3 + j] + T64[6 + i] * B64[6 + j];
+    }
+    const double s = P.block_s_d, r = P.wheel_r_d, hl = P.wheel_hl_d;
+    double best = 1e300;
+    auto sd_cyl = [&](const double* p) -> double {
+      const double rho2 = p[1] * p[1] + p[2] * p[2];
+      const double rho = sqrt64_(rho2), drad = rho - r, dax = abs_(p[0]) - hl;
+      const bool rim = (drad > 0) & (dax > 0);
+      const double dist = rim ? sqrt64_(drad * drad + dax * dax) : max_(drad, dax);
+      return rho2 < 1e-18 ? 1e300 : dist;
+    };
+    const double sb[3][3] = {{s * RTB[0], s * RTB[3], s * RTB[6]}, {s * RTB[1], s * RTB[4], s * RTB[7]}, {s * RTB[2], s * RTB[5], s * RTB[8]}};
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      double p[3];
+#pragma unroll
+      for (int q = 0; q < 3; q++) p[q] = d[q] + ((i & 1) ? sb[0][q] : -sb[0][q]) + ((i & 2) ? sb[1][q] : -sb[1][q]) + ((i & 4) ? sb[2][q] : -sb[2][q]);
+      best = min_(best, sd_cyl(p));
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const int j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+      const double dir[3] = {RTB[j], RTB[3 + j], RTB[6 + j]};
+      const double dd = dir[1] * dir[1] + dir[2] * dir[2];
+      const bool dok = !(dd < 1e-8);
+      const double idd = 1.0 / (dok ? dd : 1.0);
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        double o[3];
+#pragma unroll
+        for (int q = 0; q < 3; q++) o[q] = d[q] + ((e & 1) ? sb[j1][q] : -sb[j1][q]) + ((e & 2) ? sb[j2][q] : -sb[j2][q]);
+        const double tau = -(o[1] * dir[1] + o[2] * dir[2]) * idd;
+        const double p[3] = {o[0] + tau * dir[0], o[1] + tau * dir[1], o[2] + tau * dir[2]};
+        const double dist = sd_cyl(p);
+        best = (dok & (abs_(tau) < s)) ? min_(best, dist) : best;
+      }
+    }
+    const double rho2 = d[1] * d[1] + d[2] * d[2];
+    if (rho2 > 1e-18) {
+      const double rho = sqrt64_(rho2), ir = 1.0 / rho;
+#pragma unroll
+      for (int cand = 0; cand < 2; cand++) {
+        double xc = min_(max_(d[0], -hl), hl), rq = r;
+        if (cand == 1) { xc = d[0] >= 0 ? hl : -hl; rq = min_(rho, r); }
+        const double rel[3] = {xc - d[0], rq * d[1] * ir - d[1], rq * d[2] * ir - d[2]};
+        double p[3];
+        mulT_(RTB, rel, p);
+        const double q0 = abs_(p[0]) - s, q1 = abs_(p[1]) - s, q2 = abs_(p[2]) - s;
+        const bool outside = (q0 > 0) | (q1 > 0) | (q2 > 0);
+        const double m0 = max_(q0, 0.0), m1 = max_(q1, 0.0), m2 = max_(q2, 0.0);
+        const double dist = outside ? sqrt64_(m0 * m0 + m1 * m1 + m2 * m2) : max_(q0, max_(q1, q2));
+        best = min_(best, dist);
+      }
+    }
+    return best;
+  }
   // everything in the TORSO frame: block centre cB, block axes as columns of RTB = RT^T RB
   static BRS_HD void collide_coupled(const Params<R>& P, Store<R>& st, Frame& F, const ES& S) {
     const ContactClass<R>& c = P.cc[CC_BLOCK_ROBOT];
@@ -1343,7 +1414,14 @@ template <typename R, bool BLK> struct Sim {
       if (true) { BRS_TOC(11); return; }  // ablation only
 #endif
       if (dot_(d, d) > rr * rr) { BRS_TOC(11); return; }
-      R best = c.margin, bpos[3] = {0, 0, 0}, bn[3] = {0, 0, 1}, wq[3] = {0, 0, 0};
+#if defined(BRS_PATCH_DIST32)
+      const R wband = (R)0;
+#else
+      // candidates within 2 um BEYOND the margin are still tracked: whether the contact exists is then decided below on the
+      // distance taken from the fp64 poses (wheel_block_dist_f64), like every other contact-existence test
+      const R wband = sizeof(R) == 4 ? (R)2e-6 : (R)0;
+#endif
+      R best = c.margin + wband, bpos[3] = {0, 0, 0}, bn[3] = {0, 0, 1}, wq[3] = {0, 0, 0};
       bool found = false;
       // (a) + (b): block points against the cylinder -- only the winning POINT is tracked in the loops (4 selects per
       // candidate); its normal and contact position are rebuilt once afterwards
@@ -1424,6 +1502,13 @@ template <typename R, bool BLK> struct Sim {
           }
         }
       }
+#if !defined(BRS_PATCH_DIST32)
+      if (sizeof(R) == 4 && found && best > c.margin - wband) {  // rare: a wave skips this block
+        const double d64 = wheel_block_dist_f64(P, S, wsel);
+        found = d64 < P.margin_d[CC_BLOCK_ROBOT];
+        best = (R)d64;
+      }
+#endif
       if (found) {
         R fw[9];
         world_frame(F, bn, fw);

@@ -153,7 +153,8 @@ def test_float_build_stays_on_the_double_build_over_full_env_steps(env_id, n, st
 def test_round3_outlier_states_stay_fixed():
     """the env-steps round 3's parity campaigns found above 1e-4 (block quaternion 2.4-2.7e-4) and their causes -- the patch twist
     taken at the torso origin, an edge-axis length lost to cancellation, a discrete axis choice on fp32 roundings -- as regression
-    fixtures: the kernel source in FLOAT stays on its DOUBLE instantiation over the 250 substeps of that step"""
+    fixtures: the kernel source in FLOAT stays on its DOUBLE instantiation over the 250 substeps of that step (fourth state: the
+    wheel<->block contact existence, found by seed 5)"""
     import json, os
     from tests.hostsim.hostsim import HostSim
     fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "round3_outlier_states.json")))
